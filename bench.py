@@ -1,0 +1,156 @@
+"""bench.py - training samples/sec of the VAE posterior-consistency step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the build's counterpart of src/experiment_main/train.py:53-117 for Reg_VAE(kl_reg, alpha=1,
+beta=1): on-device mask_p draw + eps draw -> 2 x encoder + 2 x decoder forward -> ELBO + consistency loss ->
+backward -> (one flat all-reduce) -> Adam, on a synthetic batch x ~ U(0,1) [B=65 536, d=128], mask ~
+Bern(0.7), already resident in HBM.  Weak scaling: every rank steps its own B rows (global batch N*B), the
+per-step gradient all-reduce (RCCL) is inside the timed region.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus
+  roofline     - dominant kernel (vpc_decoder_fused: reparam + decoder fwd + loss + decoder bwd): algorithmic
+                 FLOP per launch / HIP-event duration measured live on the launch stream, vs the f32 MFMA peak
+  cpu_baseline - the oracle's op-for-op torch port of the reference CPU path (oracle/vae_oracle.py), timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def flops_per_sample(d, L, passes=2):
+    """Algorithmic FLOP per sample: fwd F, bwd 2F - d*H1 (no dgrad to x)."""
+    enc_f = d * 100 + 100 * 50 + 50 * 2 * L
+    dec_f = L * 50 + 50 * 100 + 100 * d
+    enc = enc_f + (2 * enc_f - d * 100)
+    dec = 3 * dec_f
+    return dict(total=2 * passes * (enc + dec), decoder_fused=2 * passes * dec, encoder_fwd=2 * passes * enc_f,
+                encoder_bwd=2 * passes * (2 * enc_f - d * 100))
+
+
+def cpu_baseline(B, d, L, seconds=20.0):
+    """Reference CPU path (port), fp32, all host threads: 2 warm-up steps + timed steps, median."""
+    from oracle import vae_oracle as O
+    torch.manual_seed(0)
+    params = O.init_params(d, L, seed=0)
+    tr = O.TorchTrainer(params, L, reg_type="kl_reg")
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, d, generator=g)
+    mask = torch.rand(B, d, generator=g) < 0.7
+    times = []
+    t_end = time.perf_counter() + seconds
+    for i in range(2 + 30):
+        t0 = time.perf_counter()
+        tr.step(x, mask, p_missingness=30, alpha=1.0, beta=1.0, epoch=1)
+        dt = time.perf_counter() - t0
+        if i >= 2:
+            times.append(dt)
+        if i >= 4 and time.perf_counter() > t_end:
+            break
+    med = statistics.median(times)
+    return dict(value=B / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(times)} steps (median) after 2 warm-up of the same B={B} d={d} Reg_VAE kl_reg step "
+                       f"(numpy mask_p draw + forward + loss + backward + Adam + .item()), anomaly-detect off",
+                ms_per_step=med * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--latent", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import vpc_amd as vpc
+    rank, world, local = vpc.dp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, d, Ld = args.batch, args.dim, args.latent
+
+    torch.manual_seed(0)
+    model = vpc.Reg_VAE(d, 500, 10, Ld, {"batch_size": B, "patience": 100}, "bench", "kl_reg").to(dev)
+    flat = model.flatten_parameters()
+    vpc.dp.broadcast_parameters(flat)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(B, d, generator=g).to(dev)
+    mask = (torch.rand(B, d, generator=g) < 0.7).to(dev)
+    tr = vpc.FusedTrainer(model, lr=1e-3, seed=rank, world_size=world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        tr.step(x, mask, alpha=1.0, beta=1.0, p_missingness=30, epoch=1)
+    sync()
+    tr.timers = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(x, mask, alpha=1.0, beta=1.0, p_missingness=30, epoch=1)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timers, tr.timers = tr.timers, None
+    total = tr.epoch_total()  # one host read per "epoch", as train.py:118
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    if not (total == total):
+        raise SystemExit("loss is NaN")
+
+    ms_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    fl = flops_per_sample(d, Ld)
+    kern_ms = {k: statistics.mean(a.elapsed_time(b) for a, b in v) for k, v in timers.items()}
+    dom = "decoder_fused"
+    achieved = fl[dom] * B / (kern_ms[dom] * 1e-3) / 1e12
+    out = {
+        "metric": "training samples/sec (ELBO+consistency step), B=65536 d=128",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"Reg_VAE kl_reg alpha=1 beta=1 training step, synthetic tabular B={B} per GPU, "
+                               f"d={d}, L={Ld}, MCAR mask 0.7, p_missingness=30, Adam lr=1e-3",
+                   "global_batch": world * B, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "vpc::dec_kernel<8,true,1> (vpc_decoder_fused)",
+                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},
+        "kernels_ms": kern_ms,
+        "step_tflops_algorithmic": fl["total"] * B / (ms_step * 1e-3) / 1e12,
+        "loss_mean": total / args.steps,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(B, d, Ld, args.cpu_seconds)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu"] = value / cb["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* vpc.h - C ABI of libvpc_hip.so: the MI355X (gfx950) kernels behind the VAE posterior-consistency
+ * training step.
+ *
+ * The reference (stschia/VAE-posterior-consistency) is pure Python and has no FFI / plugin registry; its
+ * boundary for this path is the model-class API in src/models/VAE.py.  The Python
+ * host package `vae-posterior-consistency_amd` mirrors that API and calls ONLY the entry points below
+ * (ctypes).  Each entry point names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host"; the caller owns all buffers, the
+ *    library allocates nothing and keeps no state between calls (thread-safe by statelessness);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every launch goes on it;
+ *  - return value: 0 ok, 1 bad argument, 2 unsupported shape (d > 128 or L > 15), 3 HIP runtime error.
+ *    No exceptions cross the ABI;
+ *  - fp32 tensors are row-major and exactly the reference's shapes: x, xhat [B][d]; mean, logvar, eps, z
+ *    [B][L]; masks are one byte per element (0 / non-zero), [B][d];
+ *  - `npass` = 1 (vanilla_VAE) or 2 (Reg_VAE: pass 0 = q, encoded with `mask`; pass 1 = p, encoded with
+ *    `mask_p`); per-pass pointers are passed as HOST arrays of `npass` device pointers;
+ *  - h1 [B][112] and h2 [B][64] are padded fp32 workspaces (16-byte aligned) that carry the hidden
+ *    activations from vpc_encoder_fwd to vpc_encoder_bwd;
+ *  - weights are consumed as packed "images" (see csrc/vpc_layout.h) produced by vpc_pack_weights from the
+ *    flat fp32 parameter vector in state_dict order
+ *        seq_encoder.{0,2,4}.{weight,bias}, seq_decoder.{0,2,4}.{weight,bias}   (VAE.py:366-376);
+ *  - weight gradients leave the kernels as per-workgroup partial blocks; vpc_reduce_partials turns them
+ *    into the flat gradient in the same order (deterministic summation order).
+ */
+#ifndef VPC_H
+#define VPC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- host-side layout queries (no GPU needed) --------------------------------------------------- */
+
+/* Sizes (in elements) for model (d, L).  Any out pointer may be NULL. */
+int vpc_layout_sizes(int d, int L, int* enc_img_floats, int* dec_img_floats, int* n_enc_params, int* n_params,
+                     int* enc_part_floats, int* dec_part_floats, int* loss_terms, int* tile_rows);
+
+/* HOST arrays: pack_idx[n_params] (offset of flat parameter i in the combined image [enc | dec]),
+ * grad_idx[n_params] (offset of its gradient inside an encoder (i < n_enc) / decoder partial block),
+ * img_template[enc_img_floats + dec_img_floats] (zeros plus the constant ones of the bias chain). */
+int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, float* img_template);
+
+/* Compute units of the current device = maximum number of workgroups (partial blocks) any kernel uses. */
+int vpc_num_cus(void);
+
+/* ---- parameters --------------------------------------------------------------------------------- */
+
+/* img[pack_idx[i]] = flat_params[i].  Replaces nothing in the reference (nn.Linear keeps [out][in]). */
+int vpc_pack_weights(const float* flat_params, const int* pack_idx, float* img, int n, void* stream);
+
+/* grad_out[i] = scale * sum_b partials[b * block_stride + grad_idx[i]], i < n. */
+int vpc_reduce_partials(const float* partials, int nblocks, long block_stride, const int* grad_idx,
+                        float* grad_out, int n, float scale, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps), no weight decay / amsgrad - src/experiment_main/train.py:21,116.
+ * `step` is the 1-based step count.  If pack_idx/img are non-NULL the updated value is also written into
+ * the packed image (saves the separate vpc_pack_weights launch). */
+int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
+                  float beta1, float beta2, float eps, long step, const int* pack_idx, float* img, void* stream);
+
+/* ---- encoder: Reg_VAE.encoder / vanilla_VAE.encoder, src/models/VAE.py:387-395, 1155-1163 -------- */
+
+/* For each pass p: h = MLP(x * mask[p]); mean[p], logvar[p] = chunk(h); if z[p]: z = mean + eps[p] *
+ * exp(logvar / 2) (eps[p] NULL -> z = mean, the sample=False branch).  eps / z arrays may be NULL. */
+int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
+                    const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
+                    float* const* logvar, float* const* z, long B, int d, int L, void* stream);
+
+/* Autograd of the above (src/experiment_main/train.py:115): given d loss / d mean and d loss / d logvar
+ * (with the reparameterisation path already folded in) accumulate the encoder weight gradients of all
+ * passes into partial blocks [*nblocks_out][enc_part_floats].  x needs no gradient (layer-0 dgrad skipped). */
+int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
+                    const float* const* h1, const float* const* h2, const float* const* dmean,
+                    const float* const* dlogvar, float* partials, int* nblocks_out, long B, int d, int L,
+                    void* stream);
+
+/* ---- decoder: Reg_VAE.decoder, src/models/VAE.py:397-401 ----------------------------------------- */
+
+/* xhat = sigmoid(MLP(z)) */
+int vpc_decoder_fwd(const float* z, const float* dec_img, float* xhat, long B, int d, int L, void* stream);
+
+/* Autograd of the above: (z, dxhat) -> dz [B][L] and decoder partial blocks (forward is recomputed). */
+int vpc_decoder_bwd(const float* z, const float* dxhat, const float* dec_img, float* dz, float* partials,
+                    int* nblocks_out, long B, int d, int L, void* stream);
+
+/* ---- loss ---------------------------------------------------------------------------------------- */
+/* Both loss entry points evaluate (VAE.py:403-467, 469-494, 1171-1208)
+ *   loss * B = sum_p [ cA[p] * NLL(A_p, xhat_p) + cE[p] * NLL(A_p & ~B_p, xhat_p) ]
+ *              + bq * KL(q || N(0,1)) + bp * KL(p || N(0,1)) + cr * KL(q || p) - wml * log N(z'; mu_p, var_p)
+ * with NLL(m, xhat) = sum_ij [ 0.5 log 2pi + m_ij (0.5 x_logvar + (x_ij - xhat_ij)^2 / (2 exp(x_logvar))) ]
+ * and z' = mean_q + eps_ml * exp(logvar_q / 2).  maskA/maskB are per-pass byte masks (maskB[p] may be
+ * NULL).  Per-workgroup partial sums are written as doubles, loss_partials[nblocks][8]:
+ *   0 S_A(pass 0)  1 S_E(pass 0)  2 S_A(pass 1)  3 KL0(q)  4 KL0(p)  5 KL(q||p)  6 loglik  7 S_notA(pass 0)
+ * where S_* are the NLL sums WITHOUT the 0.5 log 2pi constants.  Seeds are d(loss)/d(.) times inv_B. */
+
+/* K4: loss on materialised tensors (the model.loss(...) API).  dxhat/dmean/dlogvar NULL -> no seeds. */
+int vpc_loss_fwd_bwd(const float* x, int npass, const float* const* xhat, const uint8_t* const* maskA,
+                     const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* mean,
+                     const float* const* logvar, const float* eps_ml, float bq, float bp, float cr, float wml,
+                     float inv_B, float x_logvar, float* const* dxhat, float* const* dmean,
+                     float* const* dlogvar, double* loss_partials, int max_blocks, int* nblocks_out, long B, int d,
+                     int L, void* stream);
+
+/* Fused training path: reparameterise + decoder forward + loss + backward seeds + decoder backward in one
+ * pass (nothing of size B x d is written).  Outputs the TOTAL seeds on the encoder outputs
+ * (dmean[p], dlogvar[p], reparameterisation path included), decoder partial blocks and loss partials
+ * (term 7 unused).  Replaces VAE.py:389-392 (rsample), 397-401, 403-467 and their autograd. */
+int vpc_decoder_fused(const float* x, const float* dec_img, int npass, const uint8_t* const* maskA,
+                      const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* mean,
+                      const float* const* logvar, const float* const* eps, const float* eps_ml, float bq, float bp,
+                      float cr, float wml, float inv_B, float x_logvar, float* const* dmean,
+                      float* const* dlogvar, float* partials, double* loss_partials, int* nblocks_out, long B,
+                      int d, int L, void* stream);
+
+/* out9[0] = loss / B_global with the NLL constants of the B_local rows this rank processed (so that the
+ * sum over data-parallel ranks is the loss of the concatenated batch), out9[1..8] = the 8 raw sums;
+ * if accum != NULL, accum[0] += out9[0] (device-side epoch total, train.py:117 without a host sync). */
+int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float cE0, float cA1, float bq, float bp,
+                      float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
+                      void* stream);
+
+/* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
+
+/* mask_out = mask_in AND (U < keep_prob): create_missing_uci(shape, rate) * mask with keep_prob = 1 - rate/100
+ * (src/utils/utils.py:36-39, src/experiment_main/train.py:53-55).  mask_in NULL = all ones. */
+int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob, unsigned long long seed,
+                  unsigned long long offset, void* stream);
+
+/* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392). */
+int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPC_H */

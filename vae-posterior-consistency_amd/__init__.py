@@ -1,0 +1,16 @@
+"""MI355X-native (gfx950) VAE posterior-consistency training step.
+
+Drop-in for the hot path of stschia/VAE-posterior-consistency: the model classes keep the reference's
+Python API (src/models/VAE.py) and run on hand-written HIP kernels through the C ABI in include/vpc.h.
+The directory name is not a Python identifier; import it as `import vpc_amd` (shim at the repo root).
+"""
+from . import _lib
+from ._lib import VpcError, LIB_PATH
+from .models import Reg_VAE, vanilla_VAE, MAX_EPOCH
+from .fused import FusedTrainer
+from .harness import create_missing_uci, model_loader, checkpoint_path, train
+from . import ops
+from . import dist as dp
+
+__all__ = ["Reg_VAE", "vanilla_VAE", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train",
+           "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH"]

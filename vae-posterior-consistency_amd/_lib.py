@@ -1,0 +1,152 @@
+"""ctypes binding of libvpc_hip.so (C ABI declared in include/vpc.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a launch fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvpc_hip.so")
+
+_ERR = {1: "bad argument (null / misaligned pointer or bad count)", 2: "unsupported shape (d > 128 or L > 15)",
+        3: "HIP runtime error"}
+
+
+class VpcError(RuntimeError):
+    pass
+
+
+P = C.c_void_p
+PP = C.POINTER(C.c_void_p)
+I = C.c_int
+L_ = C.c_long
+F = C.c_float
+IP = C.POINTER(C.c_int)
+ULL = C.c_ulonglong
+
+# name -> argtypes, in the order of include/vpc.h
+_PROTOS = {
+    "vpc_layout_sizes": [I, I, IP, IP, IP, IP, IP, IP, IP, IP],
+    "vpc_build_indices": [I, I, P, P, P],
+    "vpc_num_cus": [],
+    "vpc_pack_weights": [P, P, P, I, P],
+    "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
+    "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P],
+    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, L_, I, I, P],
+    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, P, IP, L_, I, I, P],
+    "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
+    "vpc_decoder_bwd": [P, P, P, P, P, IP, L_, I, I, P],
+    "vpc_loss_fwd_bwd": [P, I, PP, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, P, F, F, F, F, F, F, PP, PP, PP, P, I,
+                         IP, L_, I, I, P],
+    "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, P, P,
+                          IP, L_, I, I, P],
+    "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
+    "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
+    "vpc_fill_normal": [P, L_, ULL, ULL, P],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises VpcError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VpcError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError here = header / library mismatch
+            fn.argtypes = argtypes
+            fn.restype = I
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_PROTOS)
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise VpcError(f"{what} failed: {_ERR.get(code, code)}")
+
+
+def ptr(t):
+    """Device / host pointer of a tensor (or None) as c_void_p."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """HOST array of pointers for the per-pass arguments."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def farray(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VpcError("this path runs only on the GPU (HIP kernels, no CPU fallback): got a CPU tensor; "
+                           "move the model and its inputs to 'cuda'")
+
+
+class Layout:
+    """Sizes and index tables of the packed layouts for one (d, L)."""
+
+    def __init__(self, d: int, L: int):
+        l = lib()
+        vals = [C.c_int() for _ in range(8)]
+        check(l.vpc_layout_sizes(d, L, *[C.byref(v) for v in vals]), "vpc_layout_sizes")
+        (self.enc_img, self.dec_img, self.n_enc, self.n_params, self.enc_part, self.dec_part, self.loss_terms,
+         self.tile_rows) = [v.value for v in vals]
+        self.d, self.L = d, L
+        self.pack_idx = np.empty(self.n_params, np.int32)
+        self.grad_idx = np.empty(self.n_params, np.int32)
+        self.img_template = np.empty(self.enc_img + self.dec_img, np.float32)
+        check(l.vpc_build_indices(d, L, self.pack_idx.ctypes.data_as(P), self.grad_idx.ctypes.data_as(P),
+                                  self.img_template.ctypes.data_as(P)), "vpc_build_indices")
+        self._dev = {}
+
+    def device_tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.pack_idx).to(device), torch.from_numpy(self.grad_idx).to(device))
+        return self._dev[key]
+
+    def nblocks(self, B: int, ncu: int) -> int:
+        return min((B + self.tile_rows - 1) // self.tile_rows, ncu)
+
+
+@lru_cache(maxsize=None)
+def layout(d: int, L: int) -> Layout:
+    return Layout(d, L)
+
+
+_NCU = None
+
+
+def num_cus() -> int:
+    global _NCU
+    if _NCU is None:
+        _NCU = int(lib().vpc_num_cus())
+    return _NCU

@@ -1,0 +1,57 @@
+"""Build libvpc_hip.so (gfx950 only) in-tree with hipcc.  Usage: python build.py [--force] [--asm]"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_misc.hip"]
+HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h"]
+LIB = os.path.join(HERE, "libvpc_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, asm=False):
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HDRS]
+    if _newer(obj, deps):
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        if asm:
+            cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if asm:
+            with open(obj + ".resource.txt", "w") as f:
+                f.write(r.stderr)
+    return obj
+
+
+def build(force=False, asm=False):
+    if force:
+        for s in SRCS:
+            o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+            if os.path.exists(o):
+                os.remove(o)
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(lambda s: _compile(s, asm), SRCS))
+    if _newer(LIB, objs):
+        r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, cwd=HERE,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, asm="--asm" in sys.argv))

@@ -1,0 +1,172 @@
+// Device-side building blocks: register-chained f32 MFMA MLP tiles (gfx950 / CDNA4 only).
+//
+// Orientation.  A wave owns 16 batch rows.  Activations are kept TRANSPOSED, feature-major:
+// an activation tile is 16 features x 16 batch rows held as one f32x4 per lane in the MFMA C/D layout
+//     lane l:  c = l & 15 (batch row inside the wave's 16),  q = l >> 4,   v[j] = act[feature 16t + 4q + j][row c]
+// which is at the same time the B-operand layout of v_mfma_f32_16x16x4_f32 for k-step j (B[k=q][n=c]).  So
+//     Y^T[out][rows] = W[out][in] * X^T[in][rows]
+// chains layer to layer entirely in registers: the weights are the A operand (from the swizzled LDS image),
+// the previous layer's accumulators are the B operand, no LDS round trip for activations.  dgrad
+// (dX^T = W^T dY^T) uses the same image through the transposed read.  Only wgrad, which contracts over the
+// batch index that sits on l & 15, needs a transpose; it goes through a small LDS staging buffer shared by
+// the 8 waves of the workgroup, each wave owning a slice of the dW accumulators for the whole kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "vpc_layout.h"
+
+namespace vpc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define VPC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+// gate(dy, act) = dy where act > 0 else 0  (ReLU backward)
+__device__ __forceinline__ f32x4 gate4(f32x4 dy, f32x4 act) {
+    return f32x4{act[0] > 0.f ? dy[0] : 0.f, act[1] > 0.f ? dy[1] : 0.f, act[2] > 0.f ? dy[2] : 0.f,
+                 act[3] > 0.f ? dy[3] : 0.f};
+}
+
+// ReLU gate as a bit mask (bit 4t+j = act tile t element j > 0): lets the activation registers die early
+template <int T>
+__device__ __forceinline__ uint32_t relu_bits(const f32x4 (&act)[T]) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b |= (act[t][j] > 0.f ? 1u : 0u) << (4 * t + j);
+    return b;
+}
+__device__ __forceinline__ f32x4 gate_bits(f32x4 dy, uint32_t bits, int t) {
+    return f32x4{(bits >> (4 * t)) & 1u ? dy[0] : 0.f, (bits >> (4 * t + 1)) & 1u ? dy[1] : 0.f,
+                 (bits >> (4 * t + 2)) & 1u ? dy[2] : 0.f, (bits >> (4 * t + 3)) & 1u ? dy[3] : 0.f};
+}
+
+// out tile mt of  W[out][in] * in   (A fragment: one ds_read_b128 per 4 MFMAs)
+template <int KT, int S>
+__device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
+                                          int q) {
+    const float* rowp = W + (16 * mt + m) * S;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ m));
+        acc = VPC_MFMA(a[0], in[kt][0], acc);
+        acc = VPC_MFMA(a[1], in[kt][1], acc);
+        acc = VPC_MFMA(a[2], in[kt][2], acc);
+        acc = VPC_MFMA(a[3], in[kt][3], acc);
+    }
+    return acc;
+}
+
+// out tile mt of  W^T[in][out] * in  where `in` has KT tiles over W's ROW index (A fragment: 4 x ds_read_b32)
+template <int KT, int S>
+__device__ __forceinline__ f32x4 tile_T(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
+                                        int q) {
+    const int col = 16 * mt + m;
+    const int cs = col >> 2, cl = col & 3;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;  // row & 15
+            const float a = W[(16 * kt + r) * S + (((cs ^ r) << 2) | cl)];
+            acc = VPC_MFMA(a, in[kt][j], acc);
+        }
+    }
+    return acc;
+}
+
+// ---- wgrad staging: stage[feat][CH] fp32, 16-byte slot XOR-swizzled with feat & (CH/4 - 1)
+template <int CH>
+__device__ __forceinline__ void stage_write(float* st, int t, f32x4 v, int colbase, int c, int q) {
+    const int col = colbase + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 16 * t + 4 * q + j;
+        st[f * CH + ((((col >> 2) ^ (f & (CH / 4 - 1))) << 2) | (col & 3))] = v[j];
+    }
+}
+template <int CH>
+__device__ __forceinline__ f32x4 stage_frag(const float* st, int t, int s, int m, int q) {
+    const int f = 16 * t + m;
+    return *reinterpret_cast<const f32x4*>(st + f * CH + 4 * ((4 * s + q) ^ (f & (CH / 4 - 1))));
+}
+
+// ---- row-major [rows][ld] global <-> C-layout tile.  Loads are branch-free: an out-of-range element reads
+// element 0 of the array (always valid) and is then replaced by 0, so the kernels stay straight-line code.
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld_tile(const float* base, long row, int ld, int f0, int nvalid, bool row_ok) {
+    const long off = row * ld + f0;
+    f32x4 v;
+    if (VEC) {  // ld % 4 == 0 and base 16-byte aligned: a 4-group is either fully valid or fully invalid
+        const bool ok = row_ok && f0 + 3 < nvalid;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? off : 0));
+        v = ok ? t : zero4();
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row_ok && f0 + j < nvalid;
+            const float t = base[ok ? off + j : 0];
+            v[j] = ok ? t : 0.f;
+        }
+    }
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void st_tile(float* base, long row, int ld, int f0, int nvalid, bool row_ok, f32x4 v) {
+    float* p = base + row * ld + f0;
+    if (VEC) {
+        if (row_ok && f0 + 3 < nvalid) *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (row_ok && f0 + j < nvalid) p[j] = v[j];
+    }
+}
+// mask bytes -> 0/1 floats for 4 consecutive features
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld_mask(const uint8_t* base, long row, int ld, int f0, int nvalid, bool row_ok) {
+    const long off = row * ld + f0;
+    f32x4 v;
+    if (VEC) {
+        const bool ok = row_ok && f0 + 3 < nvalid;
+        uint32_t u = *reinterpret_cast<const uint32_t*>(base + (ok ? off : 0));
+        u = ok ? u : 0u;
+        v = f32x4{(u & 0xffu) ? 1.f : 0.f, (u & 0xff00u) ? 1.f : 0.f, (u & 0xff0000u) ? 1.f : 0.f,
+                  (u & 0xff000000u) ? 1.f : 0.f};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row_ok && f0 + j < nvalid;
+            const uint8_t t = base[ok ? off + j : 0];
+            v[j] = (ok && t) ? 1.f : 0.f;
+        }
+    }
+    return v;
+}
+
+// copy a packed image global -> LDS (16-byte granules; n is a multiple of 4)
+__device__ __forceinline__ void load_image(float* lds, const float* img, int n) {
+    for (int i = threadIdx.x * 4; i < n; i += THREADS * 4)
+        *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(img + i);
+}
+
+// Make a lane-id derived value opaque to the optimiser.  All LDS addresses are cheap functions of (c, q);
+// without this LLVM hoists ~130 precomputed address VGPRs out of the persistent loops and spills.  Calling
+// it at the head of a phase keeps address arithmetic (a few VALU ops per ds_read) next to its use.
+__device__ __forceinline__ void launder(int& c, int& q) {
+    asm volatile("" : "+v"(c), "+v"(q));
+    __builtin_amdgcn_sched_barrier(0);  // phases are scheduled separately: bounds live ranges at 256 VGPRs
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace vpc

@@ -1,0 +1,334 @@
+// Encoder kernels (gfx950): q(z|x) MLP  d -> 100 -> 50 -> (mean | logvar), forward and backward.
+//
+// Reference semantics: Reg_VAE.encoder / vanilla_VAE.encoder, src/models/VAE.py:387-395, 1155-1163
+//   h = relu(W1 (x*mask) + b1); h = relu(W2 h + b2); mean, logvar = chunk(W3 h + b3); z = mean + eps*exp(logvar/2)
+// and its autograd (src/experiment_main/train.py:115).  See vpc_device.h for the register-chained design.
+#include "vpc_device.h"
+#include "vpc_abi_internal.h"
+
+namespace vpc {
+
+struct EncFwdArgs {
+    const float* x;
+    const float* img;
+    const uint8_t* mask[2];
+    const float* eps[2];
+    float* h1[2];
+    float* h2[2];
+    float* mean[2];
+    float* logvar[2];
+    float* z[2];
+    long B;
+    int d, L, npass, ntiles;
+};
+
+template <int DT, bool VEC>
+__global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S1 = s_for_tiles(DT);
+    const EncImg im(DT);
+    load_image(lds, a.img, im.total);
+    __syncthreads();
+    const float* W1 = lds + im.oW1;
+    const float* b1 = lds + im.ob1;
+    const float* W2 = lds + im.oW2;
+    const float* W3 = lds + im.oW3;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long row = (long)tile * TILE_ROWS + w * 16 + c;
+        const bool ok = row < a.B;
+        for (int p = 0; p < a.npass; ++p) {
+            // the weight image never changes after the prologue: without this compiler barrier LICM hoists
+            // every LDS weight read out of the pass loop and spills ~1 KB/lane of it to scratch
+            asm volatile("" ::: "memory");
+            int cc = c, qq = q;
+            launder(cc, qq);
+            f32x4 xin[DT];
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const f32x4 xv = ld_tile<VEC>(a.x, row, a.d, 16 * t + 4 * q, a.d, ok);
+                const f32x4 mk = ld_mask<VEC>(a.mask[p], row, a.d, 16 * t + 4 * q, a.d, ok);
+                xin[t] = xv * mk;  // x.float() * mask  (VAE.py:388)
+            }
+            f32x4 h1[H1T];
+#pragma unroll
+            for (int mt = 0; mt < H1T; ++mt) {
+                f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
+                acc = tile_fwd<DT, S1>(W1, mt, xin, acc, cc, qq);
+                h1[mt] = relu4(acc);
+                st_tile<true>(a.h1[p], row, H1P, 16 * mt + 4 * q, H1P, ok, h1[mt]);
+            }
+            launder(cc, qq);
+            f32x4 h2[H2T];
+#pragma unroll
+            for (int mt = 0; mt < H2T; ++mt) {
+                h2[mt] = relu4(tile_fwd<H1T, 128>(W2, mt, h1, zero4(), cc, qq));
+                st_tile<true>(a.h2[p], row, H2P, 16 * mt + 4 * q, H2P, ok, h2[mt]);
+            }
+            const f32x4 mu = tile_fwd<H2T, 64>(W3, 0, h2, zero4(), cc, qq);
+            const f32x4 lv = tile_fwd<H2T, 64>(W3, 1, h2, zero4(), cc, qq);
+            st_tile<false>(a.mean[p], row, a.L, 4 * q, a.L, ok, mu);
+            st_tile<false>(a.logvar[p], row, a.L, 4 * q, a.L, ok, lv);
+            if (a.z[p]) {
+                f32x4 z = mu;
+                if (a.eps[p]) {
+                    const f32x4 e = ld_tile<false>(a.eps[p], row, a.L, 4 * q, a.L, ok);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = mu[j] + e[j] * expf(lv[j] * 0.5f);  // rsample
+                }
+                st_tile<false>(a.z[p], row, a.L, 4 * q, a.L, ok, z);
+            }
+        }
+    }
+}
+
+struct EncBwdArgs {
+    const float* x;
+    const float* img;
+    const uint8_t* mask[2];
+    const float* h1[2];
+    const float* h2[2];
+    const float* dmean[2];
+    const float* dlogvar[2];
+    float* part;
+    long B;
+    int d, L, npass, ntiles;
+};
+
+constexpr int ENC_CH = 64;  // batch rows per wgrad staging chunk
+
+template <int DT, bool VEC>
+__global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CH = ENC_CH;
+    constexpr int WPC = CH / 16;  // waves per chunk
+    const EncImg im(DT);
+    const int nW = im.total - im.oW2;  // only W2, W3 are needed (layer 1 has no dgrad)
+    load_image(lds, a.img + im.oW2, nW);
+    float* W2 = lds;
+    float* W3 = lds + (im.oW3 - im.oW2);
+    float* stA = lds + nW;             // [112][CH]
+    float* stB = stA + H1P * CH;       // [16*DT or 112][CH]
+    constexpr int NB = (16 * DT > H1P ? 16 * DT : H1P);
+    float* db1s = stB + NB * CH;       // [128]
+    if (threadIdx.x < 128) db1s[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int colbase = 16 * (w % WPC);
+
+    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4();
+#pragma unroll
+    for (int i = 0; i < H1T; ++i) acc1[i] = zero4();
+#pragma unroll
+    for (int i = 0; i < H2T; ++i) acc2[i] = zero4();
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long row = (long)tile * TILE_ROWS + w * 16 + c;
+        const bool ok = row < a.B;
+        for (int p = 0; p < a.npass; ++p) {
+            int cc = c, qq = q;
+            launder(cc, qq);
+            f32x4 dml[2];
+            dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
+            dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
+            f32x4 h2[H2T];
+#pragma unroll
+            for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
+            // ---- dW3~ += dml * h2^T   (owner: wave w -> out tile w>>2, in tile w&3)
+            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+                __syncthreads();
+                if (w / WPC == ch) {
+                    stage_write<CH>(stA, 0, dml[0], colbase, cc, qq);
+                    stage_write<CH>(stA, 1, dml[1], colbase, cc, qq);
+#pragma unroll
+                    for (int t = 0; t < H2T; ++t) stage_write<CH>(stB, t, h2[t], colbase, cc, qq);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < WPC; ++s) {
+                    const f32x4 fa = stage_frag<CH>(stA, w >> 2, s, cc, qq);
+                    const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
+                }
+            }
+            // ---- dh2 = relu'(h2) * (W3~^T dml)
+            launder(cc, qq);
+            f32x4 dh2[H2T];
+#pragma unroll
+            for (int mt = 0; mt < H2T; ++mt) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
+            f32x4 h1[H1T];
+#pragma unroll
+            for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
+            // ---- dW2~ += dh2 * h1^T   (owner: wave w<7 -> in tile w, all 4 out tiles)
+            launder(cc, qq);
+            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+                __syncthreads();
+                if (w / WPC == ch) {
+#pragma unroll
+                    for (int t = 0; t < H2T; ++t) stage_write<CH>(stA, t, dh2[t], colbase, cc, qq);
+#pragma unroll
+                    for (int t = 0; t < H1T; ++t) stage_write<CH>(stB, t, h1[t], colbase, cc, qq);
+                }
+                __syncthreads();
+                if (w < H1T) {
+#pragma unroll
+                    for (int s = 0; s < WPC; ++s) {
+                        const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
+#pragma unroll
+                        for (int mt = 0; mt < H2T; ++mt) {
+                            const f32x4 fa = stage_frag<CH>(stA, mt, s, cc, qq);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc2[mt] = VPC_MFMA(fa[j], fb[j], acc2[mt]);
+                        }
+                    }
+                }
+            }
+            // ---- dh1 = relu'(h1) * (W2~^T dh2);  db1 += dh1
+            launder(cc, qq);
+            f32x4 dh1[H1T];
+#pragma unroll
+            for (int mt = 0; mt < H1T; ++mt) {
+                dh1[mt] = gate4(tile_T<H2T, 128>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
+                // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then
+                // one LDS float add per feature (4 distinct addresses per instruction, lanes c == 0)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = dh1[mt][j];
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 8, 64);
+                    if (c == 0) atomicAdd(&db1s[16 * mt + 4 * q + j], v);
+                }
+            }
+            f32x4 xin[DT];
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const f32x4 xv = ld_tile<VEC>(a.x, row, a.d, 16 * t + 4 * q, a.d, ok);
+                const f32x4 mk = ld_mask<VEC>(a.mask[p], row, a.d, 16 * t + 4 * q, a.d, ok);
+                xin[t] = xv * mk;
+            }
+            // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles)
+            launder(cc, qq);
+            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+                __syncthreads();
+                if (w / WPC == ch) {
+#pragma unroll
+                    for (int t = 0; t < H1T; ++t) stage_write<CH>(stA, t, dh1[t], colbase, cc, qq);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) stage_write<CH>(stB, t, xin[t], colbase, cc, qq);
+                }
+                __syncthreads();
+                if (w < DT) {
+#pragma unroll
+                    for (int s = 0; s < WPC; ++s) {
+                        const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
+#pragma unroll
+                        for (int mt = 0; mt < H1T; ++mt) {
+                            const f32x4 fa = stage_frag<CH>(stA, mt, s, cc, qq);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc1[mt] = VPC_MFMA(fa[j], fb[j], acc1[mt]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's gradient partial block
+    float* part = a.part + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < H1T; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = acc1[mt][j];
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = acc2[mt][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
+    __syncthreads();  // db1s complete (accumulated per tile through LDS float adds)
+    if (threadIdx.x < 128)
+        a.part[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = db1s[threadIdx.x];
+}
+
+static size_t enc_fwd_lds(int DT) { return sizeof(float) * EncImg(DT).total; }
+static size_t enc_bwd_lds(int DT) {
+    const EncImg im(DT);
+    const int nb = 16 * DT > H1P ? 16 * DT : H1P;
+    return sizeof(float) * ((im.total - im.oW2) + H1P * ENC_CH + nb * ENC_CH + 128);
+}
+
+template <typename K, typename A>
+static int launch(K kern, const A& args, int ntiles, size_t lds, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return VPC_ERR_HIP;
+    const int grid = ntiles < num_cus() ? ntiles : num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
+                               const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
+                               float* const* logvar, float* const* z, long B, int d, int L, void* stream) {
+    if (!x || !enc_img || !mask || !h1 || !h2 || !mean || !logvar) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    EncFwdArgs a{};
+    a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass;
+    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    bool vec = (d % 4 == 0) && aligned16(x);
+    for (int p = 0; p < npass; ++p) {
+        if (!mask[p] || !h1[p] || !h2[p] || !mean[p] || !logvar[p]) return VPC_ERR_ARG;
+        a.mask[p] = mask[p]; a.eps[p] = eps ? eps[p] : nullptr; a.h1[p] = h1[p]; a.h2[p] = h2[p];
+        a.mean[p] = mean[p]; a.logvar[p] = logvar[p]; a.z[p] = z ? z[p] : nullptr;
+        vec = vec && ((uintptr_t)mask[p] % 4 == 0);
+        if (!aligned16(h1[p]) || !aligned16(h2[p])) return VPC_ERR_ARG;
+    }
+    const int DT = dt_for(d);
+    const size_t lds = enc_fwd_lds(DT);
+    hipStream_t s = (hipStream_t)stream;
+#define VPC_CASE(T)                                                                               \
+    case T:                                                                                       \
+        return vec ? launch(enc_fwd_kernel<T, true>, a, a.ntiles, lds, s)                         \
+                   : launch(enc_fwd_kernel<T, false>, a, a.ntiles, lds, s);
+    switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+    return VPC_ERR_SHAPE;
+}
+
+extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
+                               const float* const* h1, const float* const* h2, const float* const* dmean,
+                               const float* const* dlogvar, float* partials, int* nblocks_out, long B, int d,
+                               int L, void* stream) {
+    if (!x || !enc_img || !mask || !h1 || !h2 || !dmean || !dlogvar || !partials) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    EncBwdArgs a{};
+    a.x = x; a.img = enc_img; a.part = partials; a.B = B; a.d = d; a.L = L; a.npass = npass;
+    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    bool vec = (d % 4 == 0) && aligned16(x);
+    for (int p = 0; p < npass; ++p) {
+        if (!mask[p] || !h1[p] || !h2[p] || !dmean[p] || !dlogvar[p]) return VPC_ERR_ARG;
+        a.mask[p] = mask[p]; a.h1[p] = h1[p]; a.h2[p] = h2[p]; a.dmean[p] = dmean[p]; a.dlogvar[p] = dlogvar[p];
+        vec = vec && ((uintptr_t)mask[p] % 4 == 0);
+        if (!aligned16(h1[p]) || !aligned16(h2[p])) return VPC_ERR_ARG;
+    }
+    if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
+    const int DT = dt_for(d);
+    const size_t lds = enc_bwd_lds(DT);
+    hipStream_t s = (hipStream_t)stream;
+#define VPC_CASE(T)                                                                               \
+    case T:                                                                                       \
+        return vec ? launch(enc_bwd_kernel<T, true>, a, a.ntiles, lds, s)                         \
+                   : launch(enc_bwd_kernel<T, false>, a, a.ntiles, lds, s);
+    switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+    return VPC_ERR_SHAPE;
+}

@@ -1,0 +1,440 @@
+// Small kernels and host helpers around the encoder / decoder kernels (gfx950):
+//   layout index builders (host), weight pack, gradient-partial reduction, flat Adam, loss finalisation,
+//   the stand-alone fused loss kernel (K4: mask-apply / KL / consistency distance + backward seeds),
+//   Philox4x32-10 Bernoulli keep-mask and N(0,1) generators.
+#include "vpc_device.h"
+#include "vpc_abi_internal.h"
+#include <cmath>
+#include <cstring>
+
+namespace vpc {
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+// packed row of encoder layer 3: mean rows -> tile 0, logvar rows -> tile 1
+static inline int row3(int o, int L) { return o < L ? o : 16 + (o - L); }
+
+// ------------------------------------------------------------------------------------------------
+// weight pack:  img[pack_idx[i]] = flat[i]
+__global__ void pack_kernel(const float* __restrict__ flat, const int* __restrict__ idx, float* __restrict__ img,
+                            int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) img[idx[i]] = flat[i];
+}
+
+// out[i] = scale * sum_b part[b * stride + idx[i]]   (fixed order -> bitwise reproducible)
+__global__ void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
+                              const int* __restrict__ idx, float* __restrict__ out, int n, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = part + idx[i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        s0 += p[(long)b * stride];
+        s1 += p[(long)(b + 1) * stride];
+        s2 += p[(long)(b + 2) * stride];
+        s3 += p[(long)(b + 3) * stride];
+    }
+    for (; b < nblocks; ++b) s0 += p[(long)b * stride];
+    out[i] = scale * ((s0 + s1) + (s2 + s3));
+}
+
+// torch.optim.Adam (no weight decay / amsgrad), src/experiment_main/train.py:21,116; optional re-pack
+__global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                            float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, const int* __restrict__ pack_idx, float* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i];
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pnew = param[i] - (lr / bc1) * (mi / denom);
+    param[i] = pnew;
+    if (pack_idx) img[pack_idx[i]] = pnew;
+}
+
+// loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums; accum += loss
+__global__ void loss_finalize_kernel(const double* __restrict__ lp, int nblocks, float cA0, float cE0, float cA1,
+                                     float bq, float bp, float cr, float wml, double nll_const, double inv_B,
+                                     float* __restrict__ out, float* __restrict__ accum) {
+    __shared__ double s[LOSS_TERMS];
+    if (threadIdx.x < LOSS_TERMS) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += lp[(long)b * LOSS_TERMS + threadIdx.x];
+        s[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double loss = cA0 * (s[0] + nll_const) + cE0 * (s[1] + nll_const) + cA1 * (s[2] + nll_const) +
+                            bq * s[3] + bp * s[4] + cr * s[5] - wml * s[6];
+        out[0] = (float)(loss * inv_B);
+        for (int i = 0; i < LOSS_TERMS; ++i) out[1 + i] = (float)s[i];
+        if (accum) accum[0] += (float)(loss * inv_B);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: stand-alone fused loss (API path: model.loss(...) on materialised tensors).
+// One pass over x / xhat_q / xhat_p / masks / latent stats; per-block double partials; optional seeds.
+struct LossArgs {
+    const float* x;
+    const float* xh[2];
+    const uint8_t* mA[2];
+    const uint8_t* mB[2];
+    float cA[2], cE[2];
+    const float* mean[2];
+    const float* logvar[2];
+    const float* eps_ml;
+    float* dxh[2];
+    float* dmean[2];
+    float* dlogvar[2];
+    double* loss_part;
+    float bq, bp, cr, wml, inv_B, x_logvar;
+    long n_el, n_lat;
+    int npass, want_grad, vec;
+};
+
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+    const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
+    constexpr float HL2PI = 0.91893853320467274f;
+    float S[LOSS_TERMS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    // ---- B x d part: 16-byte vector path when everything is aligned and B*d % 4 == 0, else scalar
+    const bool vec = a.vec != 0;
+    const long n4 = vec ? a.n_el / 4 : 0;
+    for (long i = tid; i < n4; i += nth) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(a.x)[i];
+        for (int p = 0; p < a.npass; ++p) {
+            const f32x4 xh = reinterpret_cast<const f32x4*>(a.xh[p])[i];
+            const uint32_t ua = reinterpret_cast<const uint32_t*>(a.mA[p])[i];
+            const uint32_t ub = a.mB[p] ? reinterpret_cast<const uint32_t*>(a.mB[p])[i] : 0u;
+            f32x4 g;
+            float sa = 0.f, se = 0.f, sn = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mA = ((ua >> (8 * j)) & 0xffu) ? 1.f : 0.f;
+                const float mB = ((ub >> (8 * j)) & 0xffu) ? 1.f : 0.f;
+                const float mE = a.mB[p] ? mA * (1.f - mB) : 0.f;
+                const float diff = xh[j] - xv[j];
+                const float t = half_lv + 0.5f * diff * diff * inv_s2;
+                sa += mA * t;
+                se += mE * t;
+                sn += (1.f - mA) * t;
+                g[j] = (a.cA[p] * mA + a.cE[p] * mE) * diff * inv_s2 * a.inv_B;
+            }
+            if (p == 0) { S[0] += sa; S[1] += se; S[7] += sn; } else { S[2] += sa; }
+            if (a.want_grad && a.dxh[p]) reinterpret_cast<f32x4*>(a.dxh[p])[i] = g;
+        }
+    }
+    if (!vec) {
+        for (long i = tid; i < a.n_el; i += nth) {
+            const float xv = a.x[i];
+            for (int p = 0; p < a.npass; ++p) {
+                const float mA = a.mA[p][i] ? 1.f : 0.f;
+                const float mE = a.mB[p] ? mA * (a.mB[p][i] ? 0.f : 1.f) : 0.f;
+                const float diff = a.xh[p][i] - xv;
+                const float t = half_lv + 0.5f * diff * diff * inv_s2;
+                if (p == 0) { S[0] += mA * t; S[1] += mE * t; S[7] += (1.f - mA) * t; } else { S[2] += mA * t; }
+                if (a.want_grad && a.dxh[p])
+                    a.dxh[p][i] = (a.cA[p] * mA + a.cE[p] * mE) * diff * inv_s2 * a.inv_B;
+            }
+        }
+    }
+    // ---- B x L part
+    for (long i = tid; i < a.n_lat; i += nth) {
+        const float mq = a.mean[0][i], lq = a.logvar[0][i];
+        const float elq = expf(lq);
+        S[3] += 0.5f * (elq + mq * mq - 1.f - lq);
+        float dmq = a.bq * mq, dlq = a.bq * 0.5f * (elq - 1.f);
+        if (a.npass == 2) {
+            const float mp = a.mean[1][i], lp = a.logvar[1][i];
+            const float elp = expf(lp), eip = expf(-lp), r = expf(lq - lp), diff = mq - mp;
+            S[4] += 0.5f * (elp + mp * mp - 1.f - lp);
+            S[5] += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+            float dmp = a.bp * mp - a.cr * diff * eip;
+            float dlp = a.bp * 0.5f * (elp - 1.f) + a.cr * 0.5f * (1.f - r - diff * diff * eip);
+            dmq += a.cr * diff * eip;
+            dlq += a.cr * 0.5f * (r - 1.f);
+            if (a.wml != 0.f) {
+                const float e3 = a.eps_ml[i], sq = expf(0.5f * lq);
+                const float dlt = mq + e3 * sq - mp;
+                S[6] += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                dmq += a.wml * dlt * eip;
+                dlq += a.wml * dlt * eip * e3 * 0.5f * sq;
+                dmp -= a.wml * dlt * eip;
+                dlp += a.wml * (0.5f - 0.5f * dlt * dlt * eip);
+            }
+            if (a.want_grad) { a.dmean[1][i] = dmp * a.inv_B; a.dlogvar[1][i] = dlp * a.inv_B; }
+        }
+        if (a.want_grad) { a.dmean[0][i] = dmq * a.inv_B; a.dlogvar[0][i] = dlq * a.inv_B; }
+    }
+    __shared__ float red[4][LOSS_TERMS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < LOSS_TERMS; ++i) {
+        const float v = wave_sum(S[i]);
+        if (lane == 0) red[w][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_TERMS) {
+        double t = 0.0;
+        for (int k = 0; k < 4; ++k) t += (double)red[k][threadIdx.x];
+        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(uint64_t ctr, uint32_t stream, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = stream, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t u) { return ((u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// mask_out = mask_in & (U < keep_prob)   (create_missing_uci * mask, utils.py:36-39 + train.py:54-55)
+__global__ void draw_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
+                                 float keep_prob, uint64_t seed, uint64_t offset) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 bytes
+    const long i0 = g * 4;
+    if (i0 >= n) return;
+    const U4 r = philox((uint64_t)g + offset, 0u, seed);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    if (i0 + 3 < n && (((uintptr_t)in | (uintptr_t)out) & 3u) == 0) {
+        const uint32_t u = in ? *reinterpret_cast<const uint32_t*>(in + i0) : 0x01010101u;
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((u >> (8 * j)) & 0xffu) && u01(rr[j]) < keep_prob) o |= 1u << (8 * j);
+        *reinterpret_cast<uint32_t*>(out + i0) = o;
+    } else {
+        for (int j = 0; j < 4 && i0 + j < n; ++j)
+            out[i0 + j] = ((in ? in[i0 + j] : 1) && u01(rr[j]) < keep_prob) ? 1 : 0;
+    }
+}
+
+__global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i0 = g * 4;
+    if (i0 >= n) return;
+    const U4 r = philox((uint64_t)g + offset, 1u, seed);
+    const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+    sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+    for (int j = 0; j < 4 && i0 + j < n; ++j) out[i0 + j] = v[j];
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+// ================================================================================================
+// host-side layout queries / index builders (no GPU needed)
+extern "C" int vpc_layout_sizes(int d, int L, int* enc_img_floats, int* dec_img_floats, int* n_enc_params,
+                                int* n_params, int* enc_part_floats, int* dec_part_floats, int* loss_terms,
+                                int* tile_rows) {
+    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    const int DT = dt_for(d);
+    const ParamOffsets po(d, L);
+    if (enc_img_floats) *enc_img_floats = EncImg(DT).total;
+    if (dec_img_floats) *dec_img_floats = DecImg(DT).total;
+    if (n_enc_params) *n_enc_params = po.n_enc;
+    if (n_params) *n_params = po.total;
+    if (enc_part_floats) *enc_part_floats = ENC_PART;
+    if (dec_part_floats) *dec_part_floats = DEC_PART;
+    if (loss_terms) *loss_terms = LOSS_TERMS;
+    if (tile_rows) *tile_rows = TILE_ROWS;
+    return VPC_OK;
+}
+
+// pack_idx[i]: offset of flat parameter i inside the combined image buffer [enc image | dec image].
+// grad_idx[i]: offset of d loss / d param_i inside the encoder (i < n_enc) or decoder partial block.
+// img_template: combined image with zeros and the constant ones of the bias chain.
+extern "C" int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, float* img_template) {
+    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (!pack_idx || !grad_idx || !img_template) return VPC_ERR_ARG;
+    const int DT = dt_for(d);
+    const EncImg ei(DT);
+    const DecImg di(DT);
+    const ParamOffsets po(d, L);
+    const int S1 = ei.S1, DB = ei.total;  // decoder image base inside the combined buffer
+    std::memset(img_template, 0, sizeof(float) * (size_t)(ei.total + di.total));
+    // ---- encoder layer 1: explicit bias; b1[100] = 1 seeds the constant chain
+    for (int o = 0; o < H1; ++o) {
+        for (int i = 0; i < d; ++i) {
+            pack_idx[po.w1 + o * d + i] = ei.oW1 + o * S1 + swz(i, o);
+            grad_idx[po.w1 + o * d + i] = part_off(i >> 4, 4 * (o >> 4), o & 15, i & 15);
+        }
+        pack_idx[po.b1 + o] = ei.ob1 + o;
+        grad_idx[po.b1 + o] = WAVES * GREGS * 64 + o;
+    }
+    img_template[ei.ob1 + H1] = 1.f;
+    // ---- encoder layer 2: bias in column 100; fake row 50 forwards the constant
+    for (int o = 0; o < H2; ++o) {
+        for (int i = 0; i <= H1; ++i) {
+            const int flat = (i < H1) ? po.w2 + o * H1 + i : po.b2 + o;
+            pack_idx[flat] = ei.oW2 + o * 128 + swz(i, o);
+            grad_idx[flat] = part_off(i >> 4, 28 + 4 * (o >> 4), o & 15, i & 15);
+        }
+    }
+    img_template[ei.oW2 + H2 * 128 + swz(H1, H2)] = 1.f;
+    // ---- encoder layer 3: mean rows -> tile 0, logvar rows -> tile 1; bias in column 50
+    for (int o = 0; o < 2 * L; ++o) {
+        const int pr = row3(o, L);
+        for (int i = 0; i <= H2; ++i) {
+            const int flat = (i < H2) ? po.w3 + o * H2 + i : po.b3 + o;
+            pack_idx[flat] = ei.oW3 + pr * 64 + swz(i, pr);
+            grad_idx[flat] = part_off((pr >> 4) * 4 + (i >> 4), 44, pr & 15, i & 15);
+        }
+    }
+    // ---- decoder layer 4: bias in column L (z[L] == 1); fake row 50 forwards the constant
+    for (int o = 0; o < H2; ++o) {
+        for (int i = 0; i <= L; ++i) {
+            const int flat = (i < L) ? po.w4 + o * L + i : po.b4 + o;
+            pack_idx[flat] = DB + di.oW4 + o * 64 + swz(i, o);
+            grad_idx[flat] = part_off(o >> 4, 44, o & 15, i & 15);
+        }
+    }
+    img_template[DB + di.oW4 + H2 * 64 + swz(L, H2)] = 1.f;
+    // ---- decoder layer 5: bias in column 50; fake row 100 forwards the constant
+    for (int o = 0; o < H1; ++o) {
+        for (int i = 0; i <= H2; ++i) {
+            const int flat = (i < H2) ? po.w5 + o * H2 + i : po.b5 + o;
+            pack_idx[flat] = DB + di.oW5 + o * 64 + swz(i, o);
+            grad_idx[flat] = part_off(o >> 4, 28 + 4 * (i >> 4), o & 15, i & 15);
+        }
+    }
+    img_template[DB + di.oW5 + H1 * 64 + swz(H2, H1)] = 1.f;
+    // ---- decoder layer 6: bias in column 100
+    for (int o = 0; o < d; ++o) {
+        for (int i = 0; i <= H1; ++i) {
+            const int flat = (i < H1) ? po.w6 + o * H1 + i : po.b6 + o;
+            pack_idx[flat] = DB + di.oW6 + o * 128 + swz(i, o);
+            grad_idx[flat] = part_off(o >> 4, 4 * (i >> 4), o & 15, i & 15);
+        }
+    }
+    return VPC_OK;
+}
+
+extern "C" int vpc_num_cus(void) { return num_cus(); }
+
+// ================================================================================================
+extern "C" int vpc_pack_weights(const float* flat_params, const int* pack_idx, float* img, int n, void* stream) {
+    if (!flat_params || !pack_idx || !img || n <= 0) return VPC_ERR_ARG;
+    hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat_params, pack_idx,
+                       img, n);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_reduce_partials(const float* partials, int nblocks, long block_stride, const int* grad_idx,
+                                   float* grad_out, int n, float scale, void* stream) {
+    if (!partials || !grad_idx || !grad_out || n <= 0 || nblocks <= 0) return VPC_ERR_ARG;
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
+                       block_stride, grad_idx, grad_out, n, scale);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
+                             float beta1, float beta2, float eps, long step, const int* pack_idx, float* img,
+                             void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return VPC_ERR_ARG;
+    if ((pack_idx == nullptr) != (img == nullptr)) return VPC_ERR_ARG;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), pack_idx,
+                       img);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float cE0, float cA1, float bq,
+                                 float bp, float cr, float wml, long B_local, long B_global, int d, float* out9,
+                                 float* accum,
+                                 void* stream) {
+    if (!loss_partials || !out9 || nblocks <= 0 || B_local <= 0 || B_global <= 0) return VPC_ERR_ARG;
+    const double nll_const = 0.91893853320467274178 * (double)B_local * (double)d;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_partials, nblocks, cA0,
+                       cE0, cA1, bq, bp, cr, wml, nll_const, 1.0 / (double)B_global, out9, accum);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_loss_fwd_bwd(const float* x, int npass, const float* const* xhat, const uint8_t* const* maskA,
+                                const uint8_t* const* maskB, const float* cA, const float* cE,
+                                const float* const* mean, const float* const* logvar, const float* eps_ml, float bq,
+                                float bp, float cr, float wml, float inv_B, float x_logvar, float* const* dxhat,
+                                float* const* dmean, float* const* dlogvar, double* loss_partials, int max_blocks,
+                                int* nblocks_out, long B, int d, int L, void* stream) {
+    if (!x || !xhat || !maskA || !cA || !cE || !mean || !logvar || !loss_partials || !nblocks_out) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0 || d < 1 || L < 1 || max_blocks < 1) return VPC_ERR_ARG;
+    if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
+    LossArgs a{};
+    a.x = x; a.eps_ml = eps_ml; a.loss_part = loss_partials;
+    a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
+    a.n_el = B * (long)d; a.n_lat = B * (long)L; a.npass = npass;
+    a.want_grad = (dxhat && dmean && dlogvar) ? 1 : 0;
+    bool al = aligned16(x);
+    for (int p = 0; p < npass; ++p) {
+        if (!xhat[p] || !maskA[p] || !mean[p] || !logvar[p]) return VPC_ERR_ARG;
+        a.xh[p] = xhat[p]; a.mA[p] = maskA[p]; a.mB[p] = maskB ? maskB[p] : nullptr; a.cA[p] = cA[p]; a.cE[p] = cE[p];
+        a.mean[p] = mean[p]; a.logvar[p] = logvar[p];
+        if (a.want_grad) {
+            if (!dmean[p] || !dlogvar[p]) return VPC_ERR_ARG;
+            a.dxh[p] = dxhat[p]; a.dmean[p] = dmean[p]; a.dlogvar[p] = dlogvar[p];
+            al = al && (!dxhat[p] || aligned16(dxhat[p]));
+        }
+        al = al && aligned16(xhat[p]) && ((uintptr_t)a.mA[p] % 4 == 0) && (!a.mB[p] || (uintptr_t)a.mB[p] % 4 == 0);
+    }
+    a.vec = (al && a.n_el % 4 == 0) ? 1 : 0;
+    long work = (B * (long)d + 3) / 4;
+    int grid = (int)((work + 255) / 256);
+    const int cap = num_cus() * 8;
+    if (grid > cap) grid = cap;
+    if (grid > max_blocks) grid = max_blocks;
+    if (grid < 1) grid = 1;
+    *nblocks_out = grid;
+    hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob,
+                             unsigned long long seed, unsigned long long offset, void* stream) {
+    if (!mask_out || n <= 0) return VPC_ERR_ARG;
+    const long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(draw_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       mask_in, mask_out, n, keep_prob, (uint64_t)seed, (uint64_t)offset);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset,
+                               void* stream) {
+    if (!out || n <= 0) return VPC_ERR_ARG;
+    const long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       out, n, (uint64_t)seed, (uint64_t)offset);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}

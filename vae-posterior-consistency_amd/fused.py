@@ -1,0 +1,181 @@
+"""Fused training step: the build's counterpart of the reference's step body
+src/experiment_main/train.py:53-117 for Reg_VAE / vanilla_VAE:
+
+    mask_p draw -> forward (2 x encoder, 2 x decoder) -> loss -> zero_grad -> backward -> Adam -> loss accumulate
+
+as 7 kernel launches and no B x d intermediate:
+
+    vpc_draw_mask            mask_p = mask & Bernoulli(1 - p_missingness/100)        (train.py:53-55)
+    vpc_fill_normal          eps_q, eps_p (, eps_ml)                                 (VAE.py:389-392)
+    vpc_encoder_fwd          both passes, writes h1/h2 workspaces + mean/logvar      (VAE.py:387-395)
+    vpc_decoder_fused        reparameterise + decoder + loss + seeds + decoder bwd   (VAE.py:397-467)
+    vpc_encoder_bwd          encoder backward of both passes                         (train.py:115)
+    vpc_reduce_partials x2   per-workgroup partial blocks -> flat gradient (deterministic order)
+      [data parallel: ONE all-reduce of the flat bucket (grads + loss terms) goes here]
+    vpc_adam_step            flat Adam + re-pack of the weight images                (train.py:114-116)
+    vpc_loss_finalize        loss scalar + device-side epoch accumulator             (train.py:117, no host sync)
+
+Gradients are those of the GLOBAL mean loss: seeds carry 1/B_global, so summing the flat bucket over ranks is
+exactly `train_loss = loss / x.shape[0]` (VAE.py:452) on the concatenated batch.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .models import MAX_EPOCH, Reg_VAE, vanilla_VAE
+from .ops import H1P, H2P, as_mask_u8
+
+
+class FusedTrainer:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+        if not isinstance(model, (Reg_VAE, vanilla_VAE)):
+            raise TypeError("FusedTrainer supports Reg_VAE and vanilla_VAE")
+        self.model = model
+        self.vanilla = isinstance(model, vanilla_VAE)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.seed = seed
+        self.rng_offset = 0
+        self.step_count = 0
+        self.pg = process_group
+        self.world_size = world_size
+        self.lay = model._lay()
+        flat = model.flatten_parameters()
+        L.require_cuda(flat)
+        self.dev = flat.device
+        n = self.lay.n_params
+        # one flat bucket: [grads (n) | loss terms (9 floats)] -> a single all-reduce per step under DP
+        self.bucket = torch.zeros(n + 9, device=self.dev)
+        self.grad = self.bucket[:n]
+        self.out9 = self.bucket[n:]
+        self.exp_avg = torch.zeros(n, device=self.dev)
+        self.exp_avg_sq = torch.zeros(n, device=self.dev)
+        self.accum = torch.zeros(1, device=self.dev)
+        ncu = L.num_cus()
+        self.partE = torch.empty(ncu * self.lay.enc_part, device=self.dev)
+        self.partD = torch.empty(ncu * self.lay.dec_part, device=self.dev)
+        self.loss_part = torch.empty(ncu, 8, dtype=torch.float64, device=self.dev)
+        self.pidx, self.gidx = self.lay.device_tables(self.dev)
+        self._ws_B = None
+        self.timers = None  # bench.py sets this to {} to collect per-kernel HIP event pairs
+        # make trainable tensors' .grad views of the flat gradient, so state is inspectable like torch's
+        off = 0
+        for p in model.trainable():
+            p.grad = self.grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    # ------------------------------------------------------------------
+    def _workspaces(self, B):
+        if self._ws_B == B:
+            return
+        dev, Ld, d = self.dev, self.lay.L, self.lay.d
+        np_ = 1 if self.vanilla else 2
+        self.h1 = [torch.empty(B, H1P, device=dev) for _ in range(np_)]
+        self.h2 = [torch.empty(B, H2P, device=dev) for _ in range(np_)]
+        self.mean = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
+        self.logvar = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
+        self.dmean = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
+        self.dlogvar = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
+        self.eps_buf = torch.empty(3, B, Ld, device=dev)
+        self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
+        self._ws_B = B
+
+    def _timed(self, name, fn, *args):
+        """Run one launch; with timers enabled bracket it with events on the launch stream."""
+        if self.timers is None:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args)
+        e1.record()
+        self.timers.setdefault(name, []).append((e0, e1))
+        return r
+
+    def coefficients(self, epoch, alpha, beta, beta_annealing):
+        """Loss coefficients of the generic form in csrc/vpc_dec.hip (VAE.py:425-446 / 1183-1195)."""
+        bw = (epoch / MAX_EPOCH) * beta if beta_annealing else beta
+        if self.vanilla:
+            return dict(cA=[1.0], cE=[0.0], bq=bw, bp=0.0, cr=0.0, wml=0.0)
+        rt = self.model.reg_type
+        if rt == "kl_reg":
+            return dict(cA=[1.0 - alpha, alpha], cE=[alpha, 0.0], bq=(1.0 - alpha) * bw, bp=alpha * bw, cr=alpha,
+                        wml=0.0)
+        if rt == "ml_reg":
+            return dict(cA=[1.0, 0.0], cE=[0.0, 0.0], bq=bw, bp=0.0, cr=0.0, wml=(epoch / MAX_EPOCH) * alpha)
+        print("Not implemented!")  # VAE.py:447-449
+        raise NotImplementedError(f"reg_type {rt!r}")
+
+    # ------------------------------------------------------------------
+    def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=1.0, beta=1.0,
+             beta_annealing=False, p_missingness=30, global_batch=None, update=True):
+        """One training step on the local rows `x` [B, d] (fp32, GPU), `mask` [B, d] (bool / uint8 / float).
+        mask_p / eps_* are drawn on the device unless injected (parity tests).  Returns nothing: the loss of
+        this step is in `self.out9[0]` (device), the running total in `self.accum` (train.py:117)."""
+        L.require_cuda(x)
+        lay, m = self.lay, self.model
+        B, d, Ld = x.shape[0], lay.d, lay.L
+        x = ops._f32c(x)
+        mask = as_mask_u8(mask)
+        self._workspaces(B)
+        Bg = global_batch if global_batch is not None else B * self.world_size
+        co = self.coefficients(epoch, alpha, beta, beta_annealing)
+        img = m._images()
+        enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
+        two = not self.vanilla
+        # ---- random draws
+        if two and mask_p is None:
+            ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset)
+            mask_p = self.mask_p_buf
+            self.rng_offset += (B * d + 3) // 4
+        elif two:
+            mask_p = as_mask_u8(mask_p)
+        need_ml = two and co["wml"] != 0.0
+        if eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None):
+            ops.fill_normal(self.eps_buf, self.seed, self.rng_offset)
+            self.rng_offset += (self.eps_buf.numel() + 3) // 4
+        eq = self.eps_buf[0] if eps_q is None else ops._f32c(eps_q)
+        ep = (self.eps_buf[1] if eps_p is None else ops._f32c(eps_p)) if two else None
+        eml = (self.eps_buf[2] if eps_ml is None else ops._f32c(eps_ml)) if need_ml else None
+        masks = [mask, mask_p] if two else [mask]
+        epss = [eq, ep] if two else [eq]
+        # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
+        self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
+                    None, d, Ld)
+        maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
+        nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
+                          self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
+                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld)
+        nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
+                          self.dlogvar, self.partE, d, Ld)
+        # ---- flat gradient + loss terms
+        ops.reduce_partials(self.partE, nbE, lay.enc_part, self.gidx[:lay.n_enc], self.grad[:lay.n_enc])
+        ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], self.grad[lay.n_enc:])
+        cA1 = co["cA"][1] if two else 0.0
+        ops.loss_finalize(self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B,
+                          Bg, d, self.out9, None)
+        if self.world_size > 1:
+            self._allreduce()
+        self.accum += self.out9[0]
+        if update:
+            self.step_count += 1
+            ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.pidx, img)
+
+    def _allreduce(self):
+        """ONE collective per step over the flat bucket [grads | loss terms] (RCCL over xGMI when the process
+        group is NCCL).  Every term is already normalised by the GLOBAL batch, so a plain SUM is the result
+        of the concatenated batch."""
+        import torch.distributed as dist
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def loss_value(self) -> float:
+        """Loss of the last step (host sync)."""
+        return float(self.out9[0].item())
+
+    def epoch_total(self, reset=True) -> float:
+        """Sum of train_loss over the steps since the last reset (train.py:117-118; one host sync per epoch)."""
+        v = float(self.accum.item())
+        if reset:
+            self.accum.zero_()
+        return v

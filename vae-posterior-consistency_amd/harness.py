@@ -1,0 +1,126 @@
+"""Harness around the model classes: the pieces of the reference's L2/L3 layers that sit on the hot path.
+
+  create_missing_uci   src/utils/utils.py:36-39      per-step Bernoulli keep-mask (device Philox instead of numpy)
+  model_loader         src/utils/loaders.py:13-246   vae_type substring dispatch + checkpoint naming
+  checkpoint_path      src/experiment_main/train.py:120-131
+  train                src/experiment_main/train.py:13-133   epoch / batch loop, Adam(lr=1e-3), save at end
+
+Only the classes named by the hot path are built (Reg_VAE, vanilla_VAE); other vae_type families raise
+NotImplementedError (out of scope).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .fused import FusedTrainer
+from .models import Reg_VAE, vanilla_VAE
+
+_seed_counter = [0]
+
+
+def create_missing_uci(shape, missing_rate, device="cuda", seed=None, offset=0):
+    """Keep-mask (True = keep) with P(keep) = 1 - missing_rate/100, drawn on the device (utils.py:36-39).
+    The reference draws from numpy's global RNG on the host; only the distribution is reproducible."""
+    out = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
+    if seed is None:
+        _seed_counter[0] += 1
+        seed, offset = 0x5EED, _seed_counter[0] * (1 << 32)
+    ops.draw_mask(None, out, 1.0 - missing_rate / 100.0, seed, offset)
+    return out.view(torch.bool)
+
+
+def _family(vae_type: str) -> str:
+    # train.py:122-124: first two '_' tokens of vae_type with the digits removed
+    return "".join(ch for ch in "_".join(vae_type.split("_")[:2]) if not ch.isdigit())
+
+
+def checkpoint_path(experiment_type, data_type, vae_type, missing_rate, alpha=1.0, p_missingness=30, reg_type="kl_reg"):
+    """File name used by train() to save and by model_loader(stage != 'train') to load (train.py:120-131)."""
+    base = os.path.join("experiments", experiment_type, data_type, "checkpoints", _family(vae_type))
+    if "vanilla" in vae_type:
+        return os.path.join(base, f"checkpoint_{vae_type}_{missing_rate}_missing_rate_test.pt")
+    return os.path.join(base, f"checkpoint_{vae_type}_{alpha}_{p_missingness}_{reg_type}_{missing_rate}"
+                              "_missing_rate_full_reg_test.pt")
+
+
+def model_loader(stage, obs_dim, hid_dim, K, latent_dim, missing_rate, data_type, training_parameters, max_epochs,
+                 num_samples, num_estimates, experiment_type, reg_type, vae_type="vae", alpha=1.0, p_missingness=30,
+                 beta=0.5, beta_annealing=True, alpha_annealing=True, not_miwae_type="changed"):
+    """Same positional signature and substring dispatch as loaders.py:13-246 for the in-scope families."""
+    if "flow" in vae_type or "notMIWAE" in vae_type or "EDDI" in vae_type or "MIWAE" in vae_type \
+            or "mask_augm" in vae_type:
+        raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* are on the accelerated path")
+    if "reg_vae" in vae_type:
+        model = Reg_VAE(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, reg_type, num_samples,
+                        num_estimates)
+    elif "vanilla_vae" in vae_type:
+        model = vanilla_VAE(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples,
+                            num_estimates)
+    else:
+        raise NotImplementedError(f"vae_type {vae_type!r}")
+    if stage == "train":
+        print("Initializing fresh model")
+    else:
+        print("Loading saved model")
+        path = checkpoint_path(experiment_type, data_type, vae_type, missing_rate, alpha, p_missingness, reg_type)
+        model.load_state_dict(torch.load(path, map_location=torch.device("cpu"), weights_only=True))
+    return model
+
+
+def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, data_type, training_parameters,
+          experiment_type, vae_type, train_k, num_estimates, max_epochs=1000, device=torch.device("cuda"), alpha=1.0,
+          stage="train", p_missingness=30, reg_type="ml_reg", beta=1.0, beta_annealing=False, alpha_annealing=True,
+          not_miwae_type="changed", fused=True, seed=0, save=True, verbose=True):
+    """train.py:13-133 for reg_vae* / vanilla_vae*.  With fused=True every batch is one FusedTrainer.step (no
+    per-step host sync: the epoch total is read once per epoch, as the reference only prints it per epoch);
+    with fused=False it is the reference's own sequence model.forward -> model.loss -> backward -> optim.Adam
+    on the API path.  Returns the trained model."""
+    model = model_loader("train", obs_dim, hid_dim, K, latent_dim, missing_rate, data_type, training_parameters,
+                         max_epochs, train_k, num_estimates, experiment_type, reg_type, vae_type, alpha=alpha,
+                         p_missingness=p_missingness)
+    model.to(device)
+    loader, _ = data_loader_train  # train.py:22-23
+    is_reg = "reg" in vae_type
+    if fused:
+        trainer = FusedTrainer(model, lr=0.001, seed=seed)
+    else:
+        model.flatten_parameters()
+        optimizer = torch.optim.Adam(model.parameters(), lr=0.001)  # train.py:21
+    for i in range(max_epochs):
+        total_loss = 0.0
+        for data_sample, mask in loader:
+            data_sample = data_sample.to(device)
+            mask = mask.to(device)
+            if fused:
+                trainer.step(data_sample, mask, epoch=i + 1, alpha=alpha, beta=beta, beta_annealing=beta_annealing,
+                             p_missingness=p_missingness)
+                continue
+            if is_reg:  # train.py:53-56, 87-94
+                mask_p = create_missing_uci(data_sample.shape, p_missingness, device=device) * mask
+                o = model.forward(data_sample, mask, mask_p, stage=stage)
+                _, train_loss = model.loss(data_sample, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mask_p,
+                                           i + 1, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
+                                           alpha_annealing=alpha_annealing, stage=stage)
+            else:  # train.py:58, 95-101
+                mask_drop = torch.ones(data_sample.shape, device=device)
+                o = model.forward(data_sample, mask * mask_drop)
+                _, train_loss = model.loss(data_sample, o[2], o[3], o[0], o[1], i + 1, mask * mask_drop,
+                                           beta_annealing=beta_annealing, beta=beta, stage=stage)
+            optimizer.zero_grad()
+            train_loss.backward()
+            optimizer.step()
+            total_loss += train_loss.item()
+        if fused:
+            total_loss = trainer.epoch_total()
+        if verbose:
+            print("Epoch: [{}/{}], Total Loss: {}".format(i, max_epochs, total_loss))
+    if save:
+        path = checkpoint_path(experiment_type, data_type, vae_type, missing_rate, alpha, p_missingness, reg_type)
+        os.makedirs(os.path.dirname(path), exist_ok=True)  # the reference never creates it
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+    print("Training is over!")
+    return model

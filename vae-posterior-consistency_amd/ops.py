@@ -1,0 +1,246 @@
+"""Thin Python wrappers over the C ABI + the autograd Functions of the API-compatible path.
+
+Every function here launches HIP kernels on torch's current stream; tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import check, farray, lib, ptr, ptr_array, require_cuda, stream_ptr
+
+H1P, H2P = 112, 64  # padded hidden widths of the h1 / h2 workspaces (csrc/vpc_layout.h)
+HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def as_mask_u8(mask: torch.Tensor) -> torch.Tensor:
+    """bool / float / uint8 mask -> contiguous uint8 (non-zero = observed)."""
+    if mask.dtype == torch.uint8:
+        m = mask
+    elif mask.dtype == torch.bool:
+        m = mask.contiguous().view(torch.uint8)
+    else:
+        m = (mask != 0).view(torch.uint8)
+    return m.contiguous()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ raw ops
+def pack_weights(flat_params, pack_idx, img):
+    check(lib().vpc_pack_weights(ptr(flat_params), ptr(pack_idx), ptr(img), flat_params.numel(), stream_ptr()),
+          "vpc_pack_weights")
+
+
+def reduce_partials(partials, nblocks, stride, grad_idx, out, scale=1.0):
+    check(lib().vpc_reduce_partials(ptr(partials), nblocks, stride, ptr(grad_idx), ptr(out), out.numel(),
+                                    float(scale), stream_ptr()), "vpc_reduce_partials")
+
+
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, pack_idx=None, img=None):
+    check(lib().vpc_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), lr, beta1, beta2, eps,
+                              int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
+
+
+def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld):
+    n = len(masks)
+    B = x.shape[0]
+    check(lib().vpc_encoder_fwd(ptr(x), ptr(enc_img), n, ptr_array(masks),
+                                ptr_array(eps) if eps is not None else None, ptr_array(h1), ptr_array(h2),
+                                ptr_array(mean), ptr_array(logvar), ptr_array(z) if z is not None else None, B, d, Ld,
+                                stream_ptr()), "vpc_encoder_fwd")
+
+
+def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld):
+    n = len(masks)
+    nb = C.c_int(0)
+    check(lib().vpc_encoder_bwd(ptr(x), ptr(enc_img), n, ptr_array(masks), ptr_array(h1), ptr_array(h2),
+                                ptr_array(dmean), ptr_array(dlogvar), ptr(partials), C.byref(nb), x.shape[0], d, Ld,
+                                stream_ptr()), "vpc_encoder_bwd")
+    return nb.value
+
+
+def decoder_fwd(z, dec_img, xhat, d, Ld):
+    check(lib().vpc_decoder_fwd(ptr(z), ptr(dec_img), ptr(xhat), z.shape[0], d, Ld, stream_ptr()), "vpc_decoder_fwd")
+
+
+def decoder_bwd(z, dxhat, dec_img, dz, partials, d, Ld):
+    nb = C.c_int(0)
+    check(lib().vpc_decoder_bwd(ptr(z), ptr(dxhat), ptr(dec_img), ptr(dz), ptr(partials), C.byref(nb), z.shape[0], d,
+                                Ld, stream_ptr()), "vpc_decoder_bwd")
+    return nb.value
+
+
+def loss_fwd_bwd(x, xhat, maskA, maskB, cA, cE, mean, logvar, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, dxhat, dmean,
+                 dlogvar, loss_part, d, Ld):
+    n = len(xhat)
+    nb = C.c_int(0)
+    want = dxhat is not None
+    check(lib().vpc_loss_fwd_bwd(ptr(x), n, ptr_array(xhat), ptr_array(maskA), ptr_array(maskB), farray(cA), farray(cE),
+                                 ptr_array(mean), ptr_array(logvar), ptr(eps_ml), bq, bp, cr, wml, inv_B, x_logvar,
+                                 ptr_array(dxhat) if want else None, ptr_array(dmean) if want else None,
+                                 ptr_array(dlogvar) if want else None, ptr(loss_part), loss_part.shape[0],
+                                 C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_loss_fwd_bwd")
+    return nb.value
+
+
+def decoder_fused(x, dec_img, maskA, maskB, cA, cE, mean, logvar, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, dmean,
+                  dlogvar, partials, loss_part, d, Ld):
+    n = len(maskA)
+    nb = C.c_int(0)
+    check(lib().vpc_decoder_fused(ptr(x), ptr(dec_img), n, ptr_array(maskA), ptr_array(maskB), farray(cA), farray(cE),
+                                  ptr_array(mean), ptr_array(logvar), ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml,
+                                  inv_B, x_logvar, ptr_array(dmean), ptr_array(dlogvar), ptr(partials), ptr(loss_part),
+                                  C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_decoder_fused")
+    return nb.value
+
+
+def loss_finalize(loss_part, nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d, out9, accum=None):
+    check(lib().vpc_loss_finalize(ptr(loss_part), nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d,
+                                  ptr(out9), ptr(accum), stream_ptr()), "vpc_loss_finalize")
+
+
+def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
+    check(lib().vpc_draw_mask(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), int(seed), int(offset),
+                              stream_ptr()), "vpc_draw_mask")
+
+
+def fill_normal(out, seed, offset):
+    check(lib().vpc_fill_normal(ptr(out), out.numel(), int(seed), int(offset), stream_ptr()), "vpc_fill_normal")
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+class EncoderFn(torch.autograd.Function):
+    """(x, mask, eps, 6 encoder tensors) -> (z, mean, logvar).  Reference: VAE.py:387-395."""
+
+    @staticmethod
+    def forward(ctx, model, x, mask_u8, eps, *weights):
+        lay = model._layout
+        d, Ld = lay.d, lay.L
+        require_cuda(x, mask_u8, eps, *weights)
+        B = x.shape[0]
+        dev = x.device
+        h1 = torch.empty(B, H1P, device=dev)
+        h2 = torch.empty(B, H2P, device=dev)
+        mean = torch.empty(B, Ld, device=dev)
+        logvar = torch.empty(B, Ld, device=dev)
+        z = torch.empty(B, Ld, device=dev)
+        encoder_fwd(x, model._enc_img(), [mask_u8], [eps], [h1], [h2], [mean], [logvar], [z], d, Ld)
+        ctx.model = model
+        ctx.save_for_backward(x, mask_u8, eps if eps is not None else torch.empty(0, device=dev), h1, h2, logvar)
+        ctx.has_eps = eps is not None
+        ctx.mark_non_differentiable()
+        return z, mean, logvar
+
+    @staticmethod
+    def backward(ctx, dz, dmean, dlogvar):
+        model = ctx.model
+        lay = model._layout
+        x, mask_u8, eps, h1, h2, logvar = ctx.saved_tensors
+        dev = x.device
+        zero = None
+        dm = dmean if dmean is not None else zero
+        dl = dlogvar if dlogvar is not None else zero
+        if dz is not None:
+            dm = dz if dm is None else dm + dz
+            if ctx.has_eps:  # z = mean + eps * exp(logvar / 2)
+                t = dz * eps * (0.5 * torch.exp(0.5 * logvar))
+                dl = t if dl is None else dl + t
+        if dm is None:
+            dm = torch.zeros_like(logvar)
+        if dl is None:
+            dl = torch.zeros_like(logvar)
+        dm, dl = dm.contiguous(), dl.contiguous()
+        part = model._partials(dev, "enc")
+        nb = encoder_bwd(x, model._enc_img(), [mask_u8], [h1], [h2], [dm], [dl], part, lay.d, lay.L)
+        flat = torch.empty(lay.n_enc, device=dev)
+        _, gidx = lay.device_tables(dev)
+        reduce_partials(part, nb, lay.enc_part, gidx[:lay.n_enc], flat)
+        grads = model._split_flat(flat, 0, 6)
+        return (None, None, None, None) + tuple(grads)
+
+
+class DecoderFn(torch.autograd.Function):
+    """(z, 6 decoder tensors) -> xhat.  Reference: VAE.py:397-401."""
+
+    @staticmethod
+    def forward(ctx, model, z, *weights):
+        lay = model._layout
+        require_cuda(z, *weights)
+        z = _f32c(z)
+        xhat = torch.empty(z.shape[0], lay.d, device=z.device)
+        decoder_fwd(z, model._dec_img(), xhat, lay.d, lay.L)
+        ctx.model = model
+        ctx.save_for_backward(z)
+        return xhat
+
+    @staticmethod
+    def backward(ctx, dxhat):
+        model = ctx.model
+        lay = model._layout
+        (z,) = ctx.saved_tensors
+        dev = z.device
+        dz = torch.empty_like(z)
+        part = model._partials(dev, "dec")
+        nb = decoder_bwd(z, dxhat.contiguous(), model._dec_img(), dz, part, lay.d, lay.L)
+        flat = torch.empty(lay.n_params - lay.n_enc, device=dev)
+        _, gidx = lay.device_tables(dev)
+        reduce_partials(part, nb, lay.dec_part, gidx[lay.n_enc:], flat)
+        grads = model._split_flat(flat, 6, 12)
+        return (None, dz) + tuple(grads)
+
+
+class LossFn(torch.autograd.Function):
+    """K4: fused ELBO / consistency loss on materialised tensors.  Returns (loss, sums[8]) where loss is the
+    reference's train_loss (already / B) and sums are the raw partial sums (see include/vpc.h)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, xq, xp, mq, lq, mp, lp, eps_ml):
+        # cfg: dict(maskA=[..], maskB=[..], cA=[..], cE=[..], bq, bp, cr, wml, x_logvar, d, L)
+        two = xp is not None
+        xs = [xq, xp] if two else [xq]
+        ms = [mq, mp] if two else [mq]
+        ls = [lq, lp] if two else [lq]
+        require_cuda(x, *xs, *ms, *ls)
+        B, d, Ld = x.shape[0], cfg["d"], cfg["L"]
+        dev = x.device
+        need_grad = any(t.requires_grad for t in xs + ms + ls)
+        dx = [torch.empty_like(t) for t in xs] if need_grad else None
+        dm = [torch.empty_like(t) for t in ms] if need_grad else None
+        dl = [torch.empty_like(t) for t in ls] if need_grad else None
+        max_blocks = L.num_cus() * 8
+        lp_buf = torch.empty(max_blocks, 8, dtype=torch.float64, device=dev)
+        nb = loss_fwd_bwd(x, xs, cfg["maskA"], cfg["maskB"], cfg["cA"], cfg["cE"], ms, ls, eps_ml, cfg["bq"], cfg["bp"],
+                          cfg["cr"], cfg["wml"], 1.0 / B, cfg["x_logvar"], dx, dm, dl, lp_buf, d, Ld)
+        sums = lp_buf[:nb].sum(0)  # float64 [8]
+        c = HALF_LOG_2PI * B * d
+        cA, cE = cfg["cA"], cfg["cE"]
+        loss = cA[0] * (sums[0] + c) + cE[0] * (sums[1] + c) + cfg["bq"] * sums[3]
+        if two:
+            loss = loss + cA[1] * (sums[2] + c) + cfg["bp"] * sums[4] + cfg["cr"] * sums[5] - cfg["wml"] * sums[6]
+        loss = (loss / B).float()
+        ctx.two = two
+        if need_grad:
+            ctx.save_for_backward(*(dx + dm + dl))
+        ctx.need_grad = need_grad
+        ctx.mark_non_differentiable(sums)
+        return loss, sums
+
+    @staticmethod
+    def backward(ctx, gloss, _gsums):
+        if not ctx.need_grad:
+            return (None,) * 9
+        t = ctx.saved_tensors
+        n = 2 if ctx.two else 1
+        dx, dm, dl = t[:n], t[n:2 * n], t[2 * n:]
+        g = [s * gloss for s in (dx + dm + dl)]
+        if ctx.two:
+            dxq, dxp, dmq, dmp, dlq, dlp = g
+            return None, None, dxq, dxp, dmq, dlq, dmp, dlp, None
+        dxq, dmq, dlq = g
+        return None, None, dxq, None, dmq, dlq, None, None, None
