@@ -111,8 +111,8 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     float* stA = lds + nW;             // [112][CH]
     float* stB = stA + H1P * CH;       // [16*DT or 112][CH]
     constexpr int NB = (16 * DT > H1P ? 16 * DT : H1P);
-    float* db1s = stB + NB * CH;       // [128]
-    if (threadIdx.x < 128) db1s[threadIdx.x] = 0.f;
+    float* db1s = stB + NB * CH;       // [WAVES][128]: per-wave bias-gradient sums (no atomics: bit-reproducible)
+    for (int i = threadIdx.x; i < WAVES * 128; i += THREADS) db1s[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * (w % WPC);
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < H1T; ++mt) {
                 dh1[mt] = gate4(tile_T<H2T, 128>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
-                // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then
-                // one LDS float add per feature (4 distinct addresses per instruction, lanes c == 0)
+                // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then the
+                // c == 0 lanes add into this wave's private LDS row (same lane every time -> fixed order)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = dh1[mt][j];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                     v += __shfl_xor(v, 2, 64);
                     v += __shfl_xor(v, 4, 64);
                     v += __shfl_xor(v, 8, 64);
-                    if (c == 0) atomicAdd(&db1s[16 * mt + 4 * q + j], v);
+                    if (c == 0) db1s[w * 128 + 16 * mt + 4 * q + j] += v;
                 }
             }
             f32x4 xin[DT];
@@ -248,16 +248,20 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
         for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = acc2[mt][j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
-    __syncthreads();  // db1s complete (accumulated per tile through LDS float adds)
-    if (threadIdx.x < 128)
-        a.part[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = db1s[threadIdx.x];
+    __syncthreads();  // every wave's db1s row is complete
+    if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) t += db1s[k * 128 + threadIdx.x];
+        a.part[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = t;
+    }
 }
 
 static size_t enc_fwd_lds(int DT) { return sizeof(float) * EncImg(DT).total; }
 static size_t enc_bwd_lds(int DT) {
     const EncImg im(DT);
     const int nb = 16 * DT > H1P ? 16 * DT : H1P;
-    return sizeof(float) * ((im.total - im.oW2) + H1P * ENC_CH + nb * ENC_CH + 128);
+    return sizeof(float) * ((im.total - im.oW2) + H1P * ENC_CH + nb * ENC_CH + WAVES * 128);
 }
 
 template <typename K, typename A>

@@ -120,7 +120,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, mask_u8, eps, *weights):
-        lay = model._layout
+        lay = model._lay()
         d, Ld = lay.d, lay.L
         require_cuda(x, mask_u8, eps, *weights)
         B = x.shape[0]
@@ -140,7 +140,7 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dmean, dlogvar):
         model = ctx.model
-        lay = model._layout
+        lay = model._lay()
         x, mask_u8, eps, h1, h2, logvar = ctx.saved_tensors
         dev = x.device
         zero = None
@@ -170,7 +170,7 @@ class DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, z, *weights):
-        lay = model._layout
+        lay = model._lay()
         require_cuda(z, *weights)
         z = _f32c(z)
         xhat = torch.empty(z.shape[0], lay.d, device=z.device)
@@ -182,7 +182,7 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxhat):
         model = ctx.model
-        lay = model._layout
+        lay = model._lay()
         (z,) = ctx.saved_tensors
         dev = z.device
         dz = torch.empty_like(z)
