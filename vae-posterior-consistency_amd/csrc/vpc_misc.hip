@@ -32,22 +32,33 @@ __global__ void pack_kernel(const float* __restrict__ flat, const int* __restric
     if (i < n) img[idx[i]] = flat[i];
 }
 
-// out[i] = scale * sum_b part[b * stride + idx[i]]   (fixed order -> bitwise reproducible)
-__global__ void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
-                              const int* __restrict__ idx, float* __restrict__ out, int n, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* p = part + idx[i];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4) {
-        s0 += p[(long)b * stride];
-        s1 += p[(long)(b + 1) * stride];
-        s2 += p[(long)(b + 2) * stride];
-        s3 += p[(long)(b + 3) * stride];
+// out[i] = scale * sum_b part[b * stride + idx[i]].  A 256-thread block handles 32 parameters x 8 block
+// groups (thread (pi, bg) sums blocks bg, bg+8, ...), then the 8 group sums are added in a fixed order:
+// bitwise reproducible, and 8x more loads in flight than one thread per parameter.
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
+                                                     const int* __restrict__ idx, float* __restrict__ out, int n,
+                                                     float scale) {
+    __shared__ float sh[8][32];
+    const int pi = threadIdx.x & 31, bg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pi;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        const float* p = part + idx[i];
+        int b = bg;
+        for (; b + 8 < nblocks; b += 16) {
+            s0 += p[(long)b * stride];
+            s1 += p[(long)(b + 8) * stride];
+        }
+        if (b < nblocks) s0 += p[(long)b * stride];
     }
-    for (; b < nblocks; ++b) s0 += p[(long)b * stride];
-    out[i] = scale * ((s0 + s1) + (s2 + s3));
+    sh[bg][pi] = s0 + s1;
+    __syncthreads();
+    if (bg == 0 && i < n) {
+        float t = sh[0][pi];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][pi];
+        out[i] = scale * t;
+    }
 }
 
 // torch.optim.Adam (no weight decay / amsgrad), src/experiment_main/train.py:21,116; optional re-pack
@@ -67,15 +78,23 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
     if (pack_idx) img[pack_idx[i]] = pnew;
 }
 
-// loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums; accum += loss
-__global__ void loss_finalize_kernel(const double* __restrict__ lp, int nblocks, float cA0, float cE0, float cA1,
-                                     float bq, float bp, float cr, float wml, double nll_const, double inv_B,
-                                     float* __restrict__ out, float* __restrict__ accum) {
+// loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums;
+// accum += loss.  256 threads: thread (term, g) sums blocks g, g+32, ...; fixed-order combine.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ lp, int nblocks, float cA0,
+                                                            float cE0, float cA1, float bq, float bp, float cr,
+                                                            float wml, double nll_const, double inv_B,
+                                                            float* __restrict__ out, float* __restrict__ accum) {
+    __shared__ double sh[32][LOSS_TERMS];
     __shared__ double s[LOSS_TERMS];
+    const int term = threadIdx.x & 7, g = threadIdx.x >> 3;
+    double t = 0.0;
+    for (int b = g; b < nblocks; b += 32) t += lp[(long)b * LOSS_TERMS + term];
+    sh[g][term] = t;
+    __syncthreads();
     if (threadIdx.x < LOSS_TERMS) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += lp[(long)b * LOSS_TERMS + threadIdx.x];
-        s[threadIdx.x] = t;
+        double u = 0.0;
+        for (int k = 0; k < 32; ++k) u += sh[k][threadIdx.x];
+        s[threadIdx.x] = u;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -354,7 +373,7 @@ extern "C" int vpc_pack_weights(const float* flat_params, const int* pack_idx, f
 extern "C" int vpc_reduce_partials(const float* partials, int nblocks, long block_stride, const int* grad_idx,
                                    float* grad_out, int n, float scale, void* stream) {
     if (!partials || !grad_idx || !grad_out || n <= 0 || nblocks <= 0) return VPC_ERR_ARG;
-    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
                        block_stride, grad_idx, grad_out, n, scale);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
@@ -378,7 +397,7 @@ extern "C" int vpc_loss_finalize(const double* loss_partials, int nblocks, float
                                  void* stream) {
     if (!loss_partials || !out9 || nblocks <= 0 || B_local <= 0 || B_global <= 0) return VPC_ERR_ARG;
     const double nll_const = 0.91893853320467274178 * (double)B_local * (double)d;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_partials, nblocks, cA0,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_partials, nblocks, cA0,
                        cE0, cA1, bq, bp, cr, wml, nll_const, 1.0 / (double)B_global, out9, accum);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }

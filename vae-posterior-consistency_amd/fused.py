@@ -153,10 +153,10 @@ class FusedTrainer:
         ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], self.grad[lay.n_enc:])
         cA1 = co["cA"][1] if two else 0.0
         ops.loss_finalize(self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B,
-                          Bg, d, self.out9, None)
+                          Bg, d, self.out9, self.accum if self.world_size == 1 else None)
         if self.world_size > 1:
             self._allreduce()
-        self.accum += self.out9[0]
+            self.accum += self.out9[0]
         if update:
             self.step_count += 1
             ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
