@@ -39,15 +39,15 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert l.vpc_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None, None, None) == 1
 
 
-def swz(col, row):
-    return (((col >> 2) ^ (row & 15)) << 2) | (col & 3)
+def swz(col, row, S=64):
+    return (((col >> 2) ^ (row & 15 & (S // 4 - 1))) << 2) | (col & 3)
 
 
 def unswizzle(img, off, rows, S):
     W = np.zeros((rows, S), np.float64)
     for r in range(rows):
         for c in range(S):
-            W[r, c] = img[off + r * S + swz(c, r)]
+            W[r, c] = img[off + r * S + swz(c, r, S)]
     return W
 
 
@@ -62,7 +62,7 @@ def images(lay, flat):
     W2 = unswizzle(img, o, 64, 128); o += 64 * 128
     W3 = unswizzle(img, o, 32, 64); o += 32 * 64
     assert o == lay.enc_img
-    W4 = unswizzle(img, o, 64, 64); o += 64 * 64
+    W4 = np.zeros((64, 64)); W4[:, :16] = unswizzle(img, o, 64, 16); o += 64 * 16
     W5 = unswizzle(img, o, 112, 64); o += 112 * 64
     W6 = unswizzle(img, o, 16 * DT, 128); o += 16 * DT * 128
     assert o == lay.enc_img + lay.dec_img
@@ -128,7 +128,7 @@ def test_packed_chain_matches_oracle(d, Ld):
     }
     encp = np.zeros(lay.enc_part); decp = np.zeros(lay.dec_part)
 
-    def scatter(block, dW, owner_reg):
+    def scatter(block, dW, owner_reg, gregs=48):
         # dW [out_pad][in_pad]; element (o, i) -> wave/reg given by owner_reg(mt, nt), C layout inside the tile
         for o in range(dW.shape[0]):
             for i in range(dW.shape[1]):
@@ -136,17 +136,18 @@ def test_packed_chain_matches_oracle(d, Ld):
                 if wave is None:
                     continue
                 ro, ci = o & 15, i & 15
-                block[(wave * 48 + reg + (ro & 3)) * 64 + (ro >> 2) * 16 + ci] += dW[o, i]
+                block[(wave * gregs + reg + (ro & 3)) * 64 + (ro >> 2) * 16 + ci] += dW[o, i]
 
     for tag, f in (("q", fq), ("p", fp)):
         dxh, dmk, dlk, eps = seeds[tag]
         dxh = dxh / B; dmk = dmk / B; dlk = dlk / B
         dpre = np.zeros((B, 16 * DT)); dpre[:, :d] = dxh * f["xh"][:, :d] * (1 - f["xh"][:, :d])
-        scatter(decp, dpre.T @ f["g2"], lambda mt, nt: (mt, 4 * nt))
+        # decoder kernel: 4 waves x 92 regs; wave = mt & 3, second out tile (mt >> 2) in the upper half
+        scatter(decp, dpre.T @ f["g2"], lambda mt, nt: (mt & 3, 28 * (mt >> 2) + 4 * nt), 92)
         dg2 = (dpre @ W6)[:, :112] * (f["g2"] > 0)
-        scatter(decp, dg2.T @ f["g1"], lambda mt, nt: (mt, 28 + 4 * nt))
+        scatter(decp, dg2.T @ f["g1"], lambda mt, nt: (mt & 3, 56 + 16 * (mt >> 2) + 4 * nt), 92)
         dg1 = (dg2 @ W5) * (f["g1"] > 0)
-        scatter(decp, dg1.T @ f["z"][:, :16], lambda mt, nt: (mt, 44))
+        scatter(decp, dg1.T @ f["z"][:, :16], lambda mt, nt: (mt, 88), 92)
         dz = (dg1 @ W4)[:, :Ld]
         dml = np.zeros((B, 32))
         dml[:, :Ld] = dmk + dz

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvpc_hip.so")
+LIB_PATH = os.environ.get("VPC_LIB") or os.path.join(_HERE, "csrc", "libvpc_hip.so")  # VPC_LIB: diagnostic builds only
 
 _ERR = {1: "bad argument (null / misaligned pointer or bad count)", 2: "unsupported shape (d > 128 or L > 15)",
         3: "HIP runtime error"}

@@ -37,6 +37,16 @@ def _compile(src, asm=False):
     return obj
 
 
+def build_ablate():
+    """Diagnostic library with the VPC_DEBUG ablation switches compiled in (never loaded by the product)."""
+    out = os.path.join(HERE, "libvpc_hip_ablate.so")
+    cmd = [HIPCC] + FLAGS + ["-DVPC_ABLATE", "-shared", "-o", out] + [os.path.join(HERE, s) for s in SRCS]
+    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def build(force=False, asm=False):
     if force:
         for s in SRCS:
@@ -54,4 +64,7 @@ def build(force=False, asm=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, asm="--asm" in sys.argv))
+    if "--ablate" in sys.argv:
+        print(build_ablate())
+    else:
+        print(build(force="--force" in sys.argv, asm="--asm" in sys.argv))

@@ -13,6 +13,7 @@
 // The additive constant 0.5*log(2 pi) per element of every NLL term is added on the host.
 #include "vpc_device.h"
 #include "vpc_abi_internal.h"
+#include <cstdlib>
 
 namespace vpc {
 
@@ -39,16 +40,36 @@ struct DecArgs {
     float bq, bp, cr, wml, inv_B, x_logvar;
     long B;
     int d, L, npass, ntiles;
+    int dbg;  // ablation mask, only honoured by the diagnostic build (-DVPC_ABLATE); 0 in the product build
 };
 
-constexpr int DEC_CH = 32;
+// VPC_DBG(bit) guards the ablation switches of the diagnostic build (tools/ablate.sh).  In the product build it
+// is an always-false test of a value the optimiser cannot see through: the switches cost one s_cbranch each
+// and, more importantly, cut the kernel's 17k-line straight-line body into scheduling regions.  hipcc's
+// scheduler otherwise hoists loads across the whole body, overshoots the 512-register budget and spills
+// (measured on MI355X: 326 us without the region cuts, 252 us with them).
+#ifdef VPC_ABLATE
+#define VPC_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+#define VPC_DBG(bit) ((opaque_zero() & (bit)) != 0)
+#endif
 
+constexpr int DEC_CH = 64;  // batch rows per wgrad staging chunk = batch tile nb of all 4 waves
+
+// One wave per SIMD (4 waves, up to 512 registers each), every wave owns NB = 2 batch tiles of 16 rows:
+// the whole per-pass live set (activations of both tiles + 92 wgrad accumulators) stays in registers, each
+// weight fragment read from LDS feeds two independent MFMA chains, and barriers involve 4 waves only.
 template <int DT, bool VEC, int MODE>
-__global__ __launch_bounds__(THREADS, 2) void dec_kernel(DecArgs a) {
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CH = DEC_CH;
-    constexpr int WPC = CH / 16;
+    constexpr int CH = DEC_CH, NB = DEC_NB;
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
+    constexpr int I6 = (DT + 3) / 4;  // dW6 out tiles per wave (mt = w + 4i)
     const DecImg im(DT);
     load_image(lds, a.img, im.total);
     const float* W4 = lds + im.oW4;
@@ -56,42 +77,53 @@ __global__ __launch_bounds__(THREADS, 2) void dec_kernel(DecArgs a) {
     const float* W6 = lds + im.oW6;
     float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
-    float* red = stB + H1P * CH;   // [WAVES][8]
+    float* red = stB + H1P * CH;   // [DEC_WAVES][8]
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
-    const int colbase = 16 * (w % WPC);
+    const int colbase = 16 * w;
     const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
     constexpr float HL2PI = 0.91893853320467274f;
 
-    f32x4 acc6[H1T], acc5[H2T], acc4 = zero4();
+    f32x4 acc6[2][H1T], acc5[2][H2T], acc4 = zero4();
 #pragma unroll
-    for (int i = 0; i < H1T; ++i) acc6[i] = zero4();
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int i = 0; i < H2T; ++i) acc5[i] = zero4();
+        for (int t = 0; t < H1T; ++t) acc6[i][t] = zero4();
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) acc5[i][t] = zero4();
+    }
     float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long row = (long)tile * TILE_ROWS + w * 16 + c;
-        const bool ok = row < a.B;
+        long row[NB];
+        bool ok[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            row[nb] = (long)tile * TILE_ROWS + w * 32 + nb * 16 + c;
+            ok[nb] = row[nb] < a.B;
+        }
         for (int p = 0; p < a.npass; ++p) {
             asm volatile("" ::: "memory");  // keep LDS weight reads inside the pass (see vpc_enc.hip)
             int cc = c, qq = q;
             launder(cc, qq);
             // ---------------- latent: z = mean + eps * exp(logvar / 2), KL terms and their seeds
-            f32x4 z[1], epsfac = zero4(), dmu_kl = zero4(), dlv_kl = zero4();
-            if (a.z_in[p]) {
-                z[0] = ld_tile<false>(a.z_in[p], row, a.L, 4 * q, a.L, ok);
-            } else {
-                const f32x4 mu = ld_tile<false>(a.mean[p], row, a.L, 4 * q, a.L, ok);
-                const f32x4 lv = ld_tile<false>(a.logvar[p], row, a.L, 4 * q, a.L, ok);
+            f32x4 z[NB][1], epsfac[NB], dmu_kl[NB], dlv_kl[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                epsfac[nb] = zero4(); dmu_kl[nb] = zero4(); dlv_kl[nb] = zero4();
+                if (a.z_in[p]) {
+                    z[nb][0] = ld_tile<false>(a.z_in[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                    continue;
+                }
+                const f32x4 mu = ld_tile<false>(a.mean[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                const f32x4 lv = ld_tile<false>(a.logvar[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
                 f32x4 e = zero4();
-                if (a.eps[p]) e = ld_tile<false>(a.eps[p], row, a.L, 4 * q, a.L, ok);
-                f32x4 sig;
+                if (a.eps[p]) e = ld_tile<false>(a.eps[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    sig[j] = expf(0.5f * lv[j]);
-                    z[0][j] = mu[j] + e[j] * sig[j];
-                    epsfac[j] = e[j] * 0.5f * sig[j];
+                    const float sig = expf(0.5f * lv[j]);
+                    z[nb][0][j] = mu[j] + e[j] * sig;
+                    epsfac[nb][j] = e[j] * 0.5f * sig;
                 }
                 if (MODE == MODE_FUSED) {
                     // Out-of-range lanes (row >= B or feature >= L) hold mu = lv = 0 for both passes, for which
@@ -100,18 +132,17 @@ __global__ __launch_bounds__(THREADS, 2) void dec_kernel(DecArgs a) {
                     const bool two = a.npass == 2;
                     f32x4 mo = zero4(), lo = zero4();
                     if (two) {
-                        mo = ld_tile<false>(a.mean[1 - p], row, a.L, 4 * q, a.L, ok);
-                        lo = ld_tile<false>(a.logvar[1 - p], row, a.L, 4 * q, a.L, ok);
+                        mo = ld_tile<false>(a.mean[1 - p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                        lo = ld_tile<false>(a.logvar[1 - p], row[nb], a.L, 4 * q, a.L, ok[nb]);
                     }
                     const float b0 = (p == 0) ? a.bq : a.bp;
-                    const float sgn = (p == 0) ? 1.f : -1.f;   // d KL(q||p) / d mu_q = -d / d mu_p
+                    const float sgn = (p == 0) ? 1.f : -1.f;  // d KL(q||p) / d mu_q = -d / d mu_p
                     const float crr = two ? a.cr : 0.f;
                     float kl0 = 0.f, klr = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float elv = expf(lv[j]);
                         kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
-                        // q / p roles: (mq, lq) is the q pass, (mp, lp) the p pass
                         const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
                         const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
                         const float diff = mq - mp, eip = expf(-lp), r = expf(lq - lp);
@@ -119,188 +150,239 @@ __global__ __launch_bounds__(THREADS, 2) void dec_kernel(DecArgs a) {
                         const float dm = b0 * mu[j] + sgn * crr * diff * eip;
                         const float dl = b0 * 0.5f * (elv - 1.f) +
                                          crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
-                        dmu_kl[j] = dm * a.inv_B;
-                        dlv_kl[j] = dl * a.inv_B;
+                        dmu_kl[nb][j] = dm * a.inv_B;
+                        dlv_kl[nb][j] = dl * a.inv_B;
                     }
                     if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
-                    if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q, scored under p (VAE.py:435-440)
-                        const f32x4 e3 = ld_tile<false>(a.eps_ml, row, a.L, 4 * q, a.L, ok);
+                    if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+                        const f32x4 e3 = ld_tile<false>(a.eps_ml, row[nb], a.L, 4 * q, a.L, ok[nb]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
+                            const bool live = ok[nb] && 4 * q + j < a.L;
                             const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
                             const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
                             const float sq = expf(0.5f * lq), eip = expf(-lp);
                             const float dlt = mq + e3[j] * sq - mp;
                             const float g = a.wml * dlt * eip * a.inv_B;
                             if (p == 0) {
-                                if (ok && 4 * q + j < a.L) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
-                                dmu_kl[j] += g;
-                                dlv_kl[j] += g * e3[j] * 0.5f * sq;
+                                if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                                dmu_kl[nb][j] += g;
+                                dlv_kl[nb][j] += g * e3[j] * 0.5f * sq;
                             } else {
-                                dmu_kl[j] -= g;
-                                dlv_kl[j] += (ok && 4 * q + j < a.L) ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
+                                dmu_kl[nb][j] -= g;
+                                dlv_kl[nb][j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
                             }
                         }
                     }
                 }
             }
             const bool skip_dec = (MODE == MODE_FUSED) && a.cA[p] == 0.f && a.cE[p] == 0.f;
-            f32x4 dzt = zero4();
+            f32x4 dzt[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) dzt[nb] = zero4();
             if (!skip_dec) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * q + j == a.L) z[0][j] = 1.f;  // constant feature that drives the bias chain
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j == a.L) z[nb][0][j] = 1.f;  // constant feature that drives the bias chain
                 // ---------------- decoder forward
-                f32x4 g1[H2T], g2[H1T];
+                f32x4 g1[NB][H2T], g2[NB][H1T];
 #pragma unroll
-                for (int mt = 0; mt < H2T; ++mt) g1[mt] = relu4(tile_fwd<1, 64>(W4, mt, z, zero4(), cc, qq));
+                for (int mt = 0; mt < H2T; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[NB] = {zero4(), zero4()};
+                    tile_fwd_nb<1, S4, NB>(W4, mt, z, acc, cc, qq);
 #pragma unroll
-                for (int mt = 0; mt < H1T; ++mt) g2[mt] = relu4(tile_fwd<H2T, 64>(W5, mt, g1, zero4(), cc, qq));
+                    for (int nb = 0; nb < NB; ++nb) g1[nb][mt] = relu4(acc[nb]);
+                }
                 launder(cc, qq);
-                f32x4 dpre[DT];
+#pragma unroll
+                for (int mt = 0; mt < H1T; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[NB] = {zero4(), zero4()};
+                    tile_fwd_nb<H2T, 64, NB>(W5, mt, g1, acc, cc, qq);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) g2[nb][mt] = relu4(acc[nb]);
+                }
+                launder(cc, qq);
+                f32x4 dpre[NB][DT];
                 float sa = 0.f, se = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);  // one output tile at a time: x / mask loads stay local
-                    const f32x4 pre = tile_fwd<H1T, 128>(W6, mt, g2, zero4(), cc, qq);
-                    f32x4 xh;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xh[j] = 1.f / (1.f + expf(-pre[j]));
+                    f32x4 pre[NB] = {zero4(), zero4()};
+                    tile_fwd_nb<H1T, 128, NB>(W6, mt, g2, pre, cc, qq);
                     const int f0 = 16 * mt + 4 * q;
-                    if (MODE == MODE_FWD) {
-                        st_tile<VEC>(a.xhat[p], row, a.d, f0, a.d, ok, xh);
-                        continue;
-                    }
-                    f32x4 dxh;
-                    if (MODE == MODE_FUSED) {
-                        const f32x4 xv = ld_tile<VEC>(a.x, row, a.d, f0, a.d, ok);
-                        const f32x4 mA = ld_mask<VEC>(a.mA[p], row, a.d, f0, a.d, ok);
-                        f32x4 mE = zero4();
-                        if (a.mB[p]) {
-                            const f32x4 mB = ld_mask<VEC>(a.mB[p], row, a.d, f0, a.d, ok);
-                            mE = mA * (1.f - mB);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        f32x4 xh;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xh[j] = 1.f / (1.f + expf(-pre[nb][j]));
+                        if (MODE == MODE_FWD) {
+                            st_tile<VEC>(a.xhat[p], row[nb], a.d, f0, a.d, ok[nb], xh);
+                            continue;
+                        }
+                        f32x4 dxh;
+                        if (MODE == MODE_FUSED && VPC_DBG(8)) {
+                            dxh = pre[nb] * a.inv_B;
+                        } else if (MODE == MODE_FUSED) {
+                            const f32x4 xv = ld_tile<VEC>(a.x, row[nb], a.d, f0, a.d, ok[nb]);
+                            const f32x4 mA = ld_mask<VEC>(a.mA[p], row[nb], a.d, f0, a.d, ok[nb]);
+                            f32x4 mE = zero4();
+                            if (a.mB[p]) {
+                                const f32x4 mB = ld_mask<VEC>(a.mB[p], row[nb], a.d, f0, a.d, ok[nb]);
+                                mE = mA * (1.f - mB);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float diff = xh[j] - xv[j];
+                                const float t = half_lv + 0.5f * diff * diff * inv_s2;
+                                sa += mA[j] * t;
+                                se += mE[j] * t;
+                                dxh[j] = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
+                            }
+                        } else {
+                            dxh = ld_tile<VEC>(a.dxhat[p], row[nb], a.d, f0, a.d, ok[nb]);
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float diff = xh[j] - xv[j];
-                            const float t = half_lv + 0.5f * diff * diff * inv_s2;
-                            sa += mA[j] * t;
-                            se += mE[j] * t;
-                            dxh[j] = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
-                        }
-                    } else {
-                        dxh = ld_tile<VEC>(a.dxhat[p], row, a.d, f0, a.d, ok);
+                        for (int j = 0; j < 4; ++j) dpre[nb][mt][j] = dxh[j] * xh[j] * (1.f - xh[j]);
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dpre[mt][j] = dxh[j] * xh[j] * (1.f - xh[j]);
                 }
                 if (MODE != MODE_FWD) {
                     if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
-                    const uint32_t gm2 = relu_bits<H1T>(g2), gm1 = relu_bits<H2T>(g1);
-                    // ---------------- dW6~ += dpre * g2^T   (owner: wave w<DT -> out tile w, 7 in tiles)
+                    uint32_t gm2[NB], gm1[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) { gm2[nb] = relu_bits<H1T>(g2[nb]); gm1[nb] = relu_bits<H2T>(g1[nb]); }
+                    // ---------------- dW6~ += dpre * g2^T   (owner: wave w -> out tiles w, w+4; all 7 in tiles)
                     launder(cc, qq);
-                    for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+#pragma unroll
+                    for (int ch = 0; ch < NB; ++ch) {
+                        if (VPC_DBG(2)) continue;
                         __syncthreads();
-                        if (w / WPC == ch) {
 #pragma unroll
-                            for (int t = 0; t < DT; ++t) stage_write<CH>(stA, t, dpre[t], colbase, cc, qq);
+                        for (int t = 0; t < DT; ++t) stage_write<CH>(stA, t, dpre[ch][t], colbase, cc, qq);
 #pragma unroll
-                            for (int t = 0; t < H1T; ++t) stage_write<CH>(stB, t, g2[t], colbase, cc, qq);
-                        }
+                        for (int t = 0; t < H1T; ++t) stage_write<CH>(stB, t, g2[ch][t], colbase, cc, qq);
                         __syncthreads();
-                        if (w < DT) {
+                        if (VPC_DBG(1)) continue;
 #pragma unroll
-                            for (int s = 0; s < WPC; ++s) {
-                                const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                        for (int s = 0; s < CH / 16; ++s) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            f32x4 fa[I6];
 #pragma unroll
-                                for (int nt = 0; nt < H1T; ++nt) {
-                                    const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
+                            for (int i = 0; i < I6; ++i) fa[i] = stage_frag<CH>(stA, (w + 4 * i) % DT, s, cc, qq);
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j) acc6[nt] = VPC_MFMA(fa[j], fb[j], acc6[nt]);
-                                }
+                            for (int nt = 0; nt < H1T; ++nt) {
+                                const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int i = 0; i < I6; ++i)
+                                        if (w + 4 * i < DT) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[j], acc6[i][nt]);
                             }
                         }
                     }
                     // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
                     launder(cc, qq);
-                    f32x4 dg2[H1T];
+                    f32x4 dg2[NB][H1T];
 #pragma unroll
-                    for (int mt = 0; mt < H1T; ++mt)
-                        dg2[mt] = gate_bits(tile_T<DT, 128>(W6, mt, dpre, zero4(), cc, qq), gm2, mt);
-                    // ---------------- dW5~ += dg2 * g1^T   (owner: wave w<7 -> out tile w, 4 in tiles)
+                    for (int mt = 0; mt < H1T; ++mt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 acc[NB] = {VPC_DBG(4) ? dpre[0][mt % DT] : zero4(), VPC_DBG(4) ? dpre[1][mt % DT] : zero4()};
+                        if (!VPC_DBG(4)) tile_T_nb<DT, 128, NB>(W6, mt, dpre, acc, cc, qq);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) dg2[nb][mt] = gate_bits(acc[nb], gm2[nb], mt);
+                    }
+                    // ---------------- dW5~ += dg2 * g1^T   (owner: wave w -> out tiles w, w+4 (<7); 4 in tiles)
                     launder(cc, qq);
-                    for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+#pragma unroll
+                    for (int ch = 0; ch < NB; ++ch) {
+                        if (VPC_DBG(2)) continue;
                         __syncthreads();
-                        if (w / WPC == ch) {
 #pragma unroll
-                            for (int t = 0; t < H1T; ++t) stage_write<CH>(stA, t, dg2[t], colbase, cc, qq);
+                        for (int t = 0; t < H1T; ++t) stage_write<CH>(stA, t, dg2[ch][t], colbase, cc, qq);
 #pragma unroll
-                            for (int t = 0; t < H2T; ++t) stage_write<CH>(stB, t, g1[t], colbase, cc, qq);
-                        }
+                        for (int t = 0; t < H2T; ++t) stage_write<CH>(stB, t, g1[ch][t], colbase, cc, qq);
                         __syncthreads();
-                        if (w < H1T) {
+                        if (VPC_DBG(1)) continue;
 #pragma unroll
-                            for (int s = 0; s < WPC; ++s) {
-                                const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                        for (int s = 0; s < CH / 16; ++s) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            f32x4 fa[2];
+                            fa[0] = stage_frag<CH>(stA, w, s, cc, qq);
+                            fa[1] = stage_frag<CH>(stA, (w + 4) % H1T, s, cc, qq);
 #pragma unroll
-                                for (int nt = 0; nt < H2T; ++nt) {
-                                    const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
+                            for (int nt = 0; nt < H2T; ++nt) {
+                                const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j) acc5[nt] = VPC_MFMA(fa[j], fb[j], acc5[nt]);
+                                for (int j = 0; j < 4; ++j) {
+                                    acc5[0][nt] = VPC_MFMA(fa[0][j], fb[j], acc5[0][nt]);
+                                    if (w + 4 < H1T) acc5[1][nt] = VPC_MFMA(fa[1][j], fb[j], acc5[1][nt]);
                                 }
                             }
                         }
                     }
                     // ---------------- dg1 = relu'(g1) * (W5~^T dg2)
                     launder(cc, qq);
-                    f32x4 dg1[H2T];
+                    f32x4 dg1[NB][H2T];
 #pragma unroll
-                    for (int mt = 0; mt < H2T; ++mt)
-                        dg1[mt] = gate_bits(tile_T<H1T, 64>(W5, mt, dg2, zero4(), cc, qq), gm1, mt);
-                    // ---------------- dW4~ += dg1 * z^T   (owner: wave w<4 -> out tile w)
+                    for (int mt = 0; mt < H2T; ++mt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 acc[NB] = {VPC_DBG(4) ? dg2[0][mt] : zero4(), VPC_DBG(4) ? dg2[1][mt] : zero4()};
+                        if (!VPC_DBG(4)) tile_T_nb<H1T, 64, NB>(W5, mt, dg2, acc, cc, qq);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) dg1[nb][mt] = gate_bits(acc[nb], gm1[nb], mt);
+                    }
+                    // ---------------- dW4~ += dg1 * z^T   (owner: wave w -> out tile w)
                     launder(cc, qq);
-                    for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
+#pragma unroll
+                    for (int ch = 0; ch < NB; ++ch) {
+                        if (VPC_DBG(2)) continue;
                         __syncthreads();
-                        if (w / WPC == ch) {
 #pragma unroll
-                            for (int t = 0; t < H2T; ++t) stage_write<CH>(stA, t, dg1[t], colbase, cc, qq);
-                            stage_write<CH>(stB, 0, z[0], colbase, cc, qq);
-                        }
+                        for (int t = 0; t < H2T; ++t) stage_write<CH>(stA, t, dg1[ch][t], colbase, cc, qq);
+                        stage_write<CH>(stB, 0, z[ch][0], colbase, cc, qq);
                         __syncthreads();
-                        if (w < H2T) {
 #pragma unroll
-                            for (int s = 0; s < WPC; ++s) {
-                                const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
-                                const f32x4 fb = stage_frag<CH>(stB, 0, s, cc, qq);
+                        for (int s = 0; s < CH / 16; ++s) {
+                            const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                            const f32x4 fb = stage_frag<CH>(stB, 0, s, cc, qq);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc4 = VPC_MFMA(fa[j], fb[j], acc4);
-                            }
+                            for (int j = 0; j < 4; ++j) acc4 = VPC_MFMA(fa[j], fb[j], acc4);
                         }
                     }
-                    dzt = tile_T<H2T, 64>(W4, 0, dg1, zero4(), cc, qq);
+                    launder(cc, qq);
+                    tile_T_nb<H2T, S4, NB>(W4, 0, dg1, dzt, cc, qq);
                 }
             }
-            if (MODE == MODE_FUSED) {
-                // total seeds on the encoder outputs: KL part + reparameterisation path
-                st_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok, dmu_kl + dzt);
-                st_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok, dlv_kl + dzt * epsfac);
-            } else if (MODE == MODE_BWD) {
-                st_tile<false>(a.dz[p], row, a.L, 4 * q, a.L, ok, dzt);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (MODE == MODE_FUSED) {
+                    // total seeds on the encoder outputs: KL part + reparameterisation path
+                    st_tile<false>(a.dmean[p], row[nb], a.L, 4 * q, a.L, ok[nb], dmu_kl[nb] + dzt[nb]);
+                    st_tile<false>(a.dlogvar[p], row[nb], a.L, 4 * q, a.L, ok[nb], dlv_kl[nb] + dzt[nb] * epsfac[nb]);
+                } else if (MODE == MODE_BWD) {
+                    st_tile<false>(a.dz[p], row[nb], a.L, 4 * q, a.L, ok[nb], dzt[nb]);
+                }
             }
         }
     }
     if (MODE == MODE_FWD) return;
-    float* part = a.part + (long)blockIdx.x * DEC_PART + (long)w * GREGS * 64 + lane;
+    float* part = a.part + (long)blockIdx.x * DEC_PART + (long)w * DEC_GREGS * 64 + lane;
 #pragma unroll
-    for (int nt = 0; nt < H1T; ++nt)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(4 * nt + j) * 64] = acc6[nt][j];
+        for (int nt = 0; nt < H1T; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < H2T; ++nt)
+            for (int j = 0; j < 4; ++j) part[(28 * i + 4 * nt + j) * 64] = acc6[i][nt][j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(28 + 4 * nt + j) * 64] = acc5[nt][j];
+        for (int nt = 0; nt < H2T; ++nt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc4[j];
+            for (int j = 0; j < 4; ++j) part[(56 + 16 * i + 4 * nt + j) * 64] = acc5[i][nt][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
     if (MODE == MODE_FUSED) {
         const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
         __syncthreads();
@@ -312,7 +394,7 @@ __global__ __launch_bounds__(THREADS, 2) void dec_kernel(DecArgs a) {
         __syncthreads();
         if (threadIdx.x < LOSS_TERMS) {
             double t = 0.0;
-            for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+            for (int k = 0; k < DEC_WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
             a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
         }
     }
@@ -322,7 +404,7 @@ static size_t dec_lds(int DT, int mode) {
     const DecImg im(DT);
     if (mode == MODE_FWD) return sizeof(float) * im.total;
     const int na = 16 * DT > H1P ? 16 * DT : H1P;
-    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + WAVES * LOSS_TERMS);
+    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + DEC_WAVES * LOSS_TERMS);
 }
 
 template <typename K>
@@ -331,7 +413,7 @@ static int launch(K kern, const DecArgs& args, size_t lds, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return VPC_ERR_HIP;
     const int grid = args.ntiles < num_cus() ? args.ntiles : num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC_THREADS), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -397,6 +479,9 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
     a.B = B; a.d = d; a.L = L; a.npass = npass;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+#ifdef VPC_ABLATE
+    if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
+#endif
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
         if (!maskA[p] || !mean[p] || !logvar[p] || !dmean[p] || !dlogvar[p]) return VPC_ERR_ARG;

@@ -46,6 +46,40 @@ __device__ __forceinline__ f32x4 gate_bits(f32x4 dy, uint32_t bits, int t) {
                  (bits >> (4 * t + 2)) & 1u ? dy[2] : 0.f, (bits >> (4 * t + 3)) & 1u ? dy[3] : 0.f};
 }
 
+// ---- NB batch tiles per wave (decoder kernel, one wave per SIMD): one A fragment feeds NB independent
+// accumulator chains, which hides the 40-cycle dependent-MFMA latency without a second wave on the SIMD.
+template <int KT, int S, int NB>
+__device__ __forceinline__ void tile_fwd_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB],
+                                            int m, int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const float* rowp = W + (16 * mt + m) * S;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[j], in[nb][kt][j], acc[nb]);
+    }
+}
+template <int KT, int S, int NB>
+__device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB], int m,
+                                          int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const int col = 16 * mt + m;
+    const int cs = col >> 2, cl = col & 3;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            const float a = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a, in[nb][kt][j], acc[nb]);
+        }
+    }
+}
+
 // out tile mt of  W[out][in] * in   (A fragment: one ds_read_b128 per 4 MFMAs)
 template <int KT, int S>
 __device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
@@ -149,10 +183,25 @@ __device__ __forceinline__ f32x4 ld_mask(const uint8_t* base, long row, int ld, 
     return v;
 }
 
-// copy a packed image global -> LDS (16-byte granules; n is a multiple of 4)
+// copy a packed image global -> LDS (16-byte granules; n is a multiple of 4).  8 loads are kept in flight per
+// thread: a naive load->store loop pays one full memory latency per 16 bytes per thread (tens of us for a
+// 100 KB image, once per workgroup).
 __device__ __forceinline__ void load_image(float* lds, const float* img, int n) {
-    for (int i = threadIdx.x * 4; i < n; i += THREADS * 4)
-        *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(img + i);
+    constexpr int U = 8;
+    const int step = blockDim.x * 4;
+    for (int base = threadIdx.x * 4; base < n; base += step * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * step;
+            v[u] = *reinterpret_cast<const f32x4*>(img + (i < n ? i : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * step;
+            if (i < n) *reinterpret_cast<f32x4*>(lds + i) = v[u];
+        }
+    }
 }
 
 // Make a lane-id derived value opaque to the optimiser.  All LDS addresses are cheap functions of (c, q);

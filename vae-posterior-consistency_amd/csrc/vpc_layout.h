@@ -6,8 +6,9 @@
 //   d   -> DT tiles (DT = 1, 2, 4 or 8, i.e. d <= 128)
 //   100 -> 7 tiles (112),  50 -> 4 tiles (64),  2L -> 2 tiles (mean tile | logvar tile),  L -> 1 tile
 //
-// A weight image is W~[out_pad][S] fp32 with S a multiple of 64 dwords and the 16-byte slot index
-// XOR-swizzled with (row & 15): phys_col = (((col>>2) ^ (row&15)) << 2) | (col&3).  That makes both the
+// A weight image is W~[out_pad][S] fp32 with S = 64 or 128 dwords (16 for the tiny decoder layer 4) and the
+// 16-byte slot index XOR-swizzled with row & min(15, S/4 - 1): phys_col = (((col>>2) ^ (row&15)) << 2) | (col&3)
+// for S >= 64.  That makes both the
 // forward A-fragment read (ds_read_b128, lane (m,q) -> row m, cols 16kt+4q..+3) and the transposed
 // A-fragment read used by dgrad (ds_read_b32, lane (m,q) -> row 16kt+4q+j, col m) conflict-free
 // (tools/lds_conflicts.py).
@@ -38,7 +39,9 @@ constexpr int MAX_D = 128, MAX_L = 15;
 
 VPC_HD constexpr int dt_for(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 8; }
 VPC_HD constexpr int s_for_tiles(int t) { return t > 4 ? 128 : 64; }
-VPC_HD inline int swz(int col, int row) { return ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
+VPC_HD inline int swz(int col, int row, int S = 64) {
+    return ((((col >> 2) ^ (row & 15 & (S / 4 - 1))) << 2) | (col & 3));
+}
 
 // ---- encoder image: [W1: 112 x S1][b1: 128][W2: 64 x 128][W3: 32 x 64]
 struct EncImg {
@@ -48,27 +51,31 @@ struct EncImg {
         oW1 = 0; ob1 = oW1 + H1P * S1; oW2 = ob1 + 128; oW3 = oW2 + H2P * 128; total = oW3 + 32 * 64;
     }
 };
-// ---- decoder image: [W4: 64 x 64][W5: 112 x 64][W6: 16*DT x 128]
+// ---- decoder image: [W4: 64 x 16][W5: 112 x 64][W6: 16*DT x 128]
+constexpr int S4 = 16;
 struct DecImg {
     int DT, oW4, oW5, oW6, total;
     VPC_HD explicit DecImg(int dt) {
-        DT = dt; oW4 = 0; oW5 = oW4 + H2P * 64; oW6 = oW5 + H1P * 64; total = oW6 + 16 * dt * 128;
+        DT = dt; oW4 = 0; oW5 = oW4 + H2P * S4; oW6 = oW5 + H1P * 64; total = oW6 + 16 * dt * 128;
     }
 };
 
 // ---- gradient partial block written by each workgroup (floats).  Register r of lane l of wave w lives at
 // (w * REGS + r) * 64 + l; a 16x16 dW tile in C layout: element (row 4q+j, col c) = reg j of lane 16q+c.
-// decoder kernel: dW6 tile (mt=w, nt) -> regs 4nt..4nt+3 (nt<7); dW5 tile (mt=w<7, nt<4) -> 28+4nt..;
-//                 dW4 tile (mt=w<4) -> 44..47
-// encoder kernel: dW1 tile (mt<7, nt=w) -> regs 4mt..; dW2 tile (mt<4, nt=w<7) -> 28+4mt..;
+// encoder kernel (8 waves x 48 regs): dW1 tile (mt<7, nt=w) -> regs 4mt..; dW2 tile (mt<4, nt=w<7) -> 28+4mt..;
 //                 dW3 tile (mt=w>>2 (<2), nt=w&3) -> 44..47;  db1[112] appended after the 8 wave blocks.
+// decoder kernel (4 waves x 92 regs, one wave per SIMD, 2 batch tiles per wave):
+//                 dW6 tile (mt = w + 4i, nt<7) -> regs 28i + 4nt..;  dW5 tile (mt = w + 4i < 7, nt<4) ->
+//                 56 + 16i + 4nt..;  dW4 tile (mt = w) -> 88..91
 constexpr int GREGS = 48;
-constexpr int DEC_PART = WAVES * GREGS * 64;          // 24576 floats
 constexpr int ENC_PART = WAVES * GREGS * 64 + 128;    // + db1
+constexpr int DEC_WAVES = 4, DEC_NB = 2, DEC_THREADS = DEC_WAVES * 64;
+constexpr int DEC_GREGS = 92;
+constexpr int DEC_PART = DEC_WAVES * DEC_GREGS * 64;  // 23552 floats
 constexpr int LOSS_TERMS = 8;                          // doubles per workgroup
 
-VPC_HD inline int part_off(int wave, int reg, int row_in_tile, int col_in_tile) {
-    return (wave * GREGS + reg + (row_in_tile & 3)) * 64 + ((row_in_tile >> 2) * 16 + col_in_tile);
+VPC_HD inline int part_off(int wave, int reg, int row_in_tile, int col_in_tile, int gregs = GREGS) {
+    return (wave * gregs + reg + (row_in_tile & 3)) * 64 + ((row_in_tile >> 2) * 16 + col_in_tile);
 }
 
 // flat parameter order == state_dict order of the 12 trainable tensors

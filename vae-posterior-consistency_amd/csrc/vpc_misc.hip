@@ -335,17 +335,17 @@ extern "C" int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, flo
     for (int o = 0; o < H2; ++o) {
         for (int i = 0; i <= L; ++i) {
             const int flat = (i < L) ? po.w4 + o * L + i : po.b4 + o;
-            pack_idx[flat] = DB + di.oW4 + o * 64 + swz(i, o);
-            grad_idx[flat] = part_off(o >> 4, 44, o & 15, i & 15);
+            pack_idx[flat] = DB + di.oW4 + o * S4 + swz(i, o, S4);
+            grad_idx[flat] = part_off(o >> 4, 88, o & 15, i & 15, DEC_GREGS);
         }
     }
-    img_template[DB + di.oW4 + H2 * 64 + swz(L, H2)] = 1.f;
+    img_template[DB + di.oW4 + H2 * S4 + swz(L, H2, S4)] = 1.f;
     // ---- decoder layer 5: bias in column 50; fake row 100 forwards the constant
     for (int o = 0; o < H1; ++o) {
         for (int i = 0; i <= H2; ++i) {
             const int flat = (i < H2) ? po.w5 + o * H2 + i : po.b5 + o;
             pack_idx[flat] = DB + di.oW5 + o * 64 + swz(i, o);
-            grad_idx[flat] = part_off(o >> 4, 28 + 4 * (i >> 4), o & 15, i & 15);
+            grad_idx[flat] = part_off((o >> 4) & 3, 56 + 16 * (o >> 6) + 4 * (i >> 4), o & 15, i & 15, DEC_GREGS);
         }
     }
     img_template[DB + di.oW5 + H1 * 64 + swz(H2, H1)] = 1.f;
@@ -354,7 +354,7 @@ extern "C" int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, flo
         for (int i = 0; i <= H1; ++i) {
             const int flat = (i < H1) ? po.w6 + o * H1 + i : po.b6 + o;
             pack_idx[flat] = DB + di.oW6 + o * 128 + swz(i, o);
-            grad_idx[flat] = part_off(o >> 4, 4 * (i >> 4), o & 15, i & 15);
+            grad_idx[flat] = part_off((o >> 4) & 3, 28 * (o >> 6) + 4 * (i >> 4), o & 15, i & 15, DEC_GREGS);
         }
     }
     return VPC_OK;
