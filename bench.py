@@ -41,9 +41,14 @@ def flops_per_sample(d, L, passes=2):
                 encoder_bwd=2 * passes * (2 * enc_f - d * 100))
 
 
-def cpu_baseline(B, d, L, seconds=20.0):
-    """Reference CPU path (port), fp32, all host threads: 2 warm-up steps + timed steps, median."""
+def cpu_baseline(B, d, L, seconds=20.0, threads=None):
+    """Reference CPU path (port), fp32: 2 warm-up steps + timed steps, median.  `threads` defaults to the cores
+    this job may use (the GPU box gives a 1-GPU job a 16-core share of a 128-core host; torch's default of 128
+    threads oversubscribes that share 8x and runs the step 6x slower, so it is capped at 16)."""
     from oracle import vae_oracle as O
+    if threads is None:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     params = O.init_params(d, L, seed=0)
     tr = O.TorchTrainer(params, L, reg_type="kl_reg")
@@ -77,6 +82,7 @@ def main():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=None)
     args = ap.parse_args()
 
     import vpc_amd as vpc
@@ -146,7 +152,7 @@ def main():
         "loss_mean": total / args.steps,
     }
     if world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(B, d, Ld, args.cpu_seconds)
+        cb = cpu_baseline(B, d, Ld, args.cpu_seconds, args.cpu_threads)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu"] = value / cb["value"]
     print(json.dumps(out))

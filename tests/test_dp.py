@@ -1,0 +1,145 @@
+"""Data-parallel path: world_size-2 process groups over gloo on 127.0.0.1.
+
+* CPU test: the bucket contract of dist.py - every rank contributes grads / loss terms of its row shard
+  normalised by the GLOBAL batch; one all_reduce(SUM) equals the single-process result on the concatenated
+  batch.  The per-rank producer here is the oracle (test infrastructure); the product wires the same bucket to
+  the HIP kernels (FusedTrainer).
+* GPU test: the real FusedTrainer on two ranks sharing cuda:0 (gloo moves the bucket), 3 optimiser steps,
+  against a single-process FusedTrainer on the full batch.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import vpc_amd as vpc
+from oracle import vae_oracle as O
+
+L = 10
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(B, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, d, generator=g)
+    mask = torch.rand(B, d, generator=g) < 0.7
+    mask_p = mask & (torch.rand(B, d, generator=g) < 0.7)
+    return x, mask, mask_p, torch.randn(B, L, generator=g), torch.randn(B, L, generator=g)
+
+
+def _cpu_worker(rank, world, port, d, B, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, w, _ = vpc.dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    params = O.init_params(d, L, seed=5)
+    flat = torch.cat([params[k].reshape(-1) for k in O.PARAM_KEYS])
+    if rank != 0:
+        flat = torch.zeros_like(flat)  # replicas start from rank 0's weights
+    vpc.dp.broadcast_parameters(flat)
+    off, p = 0, {}
+    for k in O.PARAM_KEYS:
+        n = params[k].numel()
+        p[k] = flat[off:off + n].view_as(params[k]); off += n
+    x, mask, mask_p, eq, ep = _inputs(B, d)
+    lo, hi = vpc.dp.shard_rows(B, rank, world)
+    loss_l, grads_l, _, _ = O.closed_form_reg_step(p, L, x[lo:hi], mask[lo:hi], mask_p[lo:hi], eq[lo:hi], ep[lo:hi],
+                                                   alpha=0.8, beta=0.9)
+    scale = (hi - lo) / B  # local mean -> contribution to the global mean (seeds carry 1/B_global)
+    bucket = torch.cat([torch.from_numpy(np.concatenate([grads_l[k].reshape(-1) for k in O.PARAM_KEYS]) * scale),
+                        torch.tensor([loss_l * scale], dtype=torch.float64)])
+    vpc.dp.allreduce_bucket(bucket)
+    if rank == 0:
+        out.put(bucket.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,B", [(14, 37), (128, 64)])
+def test_bucket_allreduce_equals_single_process_gloo(d, B):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, d, B, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    params = O.init_params(d, L, seed=5)
+    x, mask, mask_p, eq, ep = _inputs(B, d)
+    loss, grads, _, _ = O.closed_form_reg_step(params, L, x, mask, mask_p, eq, ep, alpha=0.8, beta=0.9)
+    want = np.concatenate([np.concatenate([grads[k].reshape(-1) for k in O.PARAM_KEYS]), [loss]])
+    assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.max(np.abs(want)))
+
+
+def test_shard_rows_partition():
+    for n in (1, 7, 128, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            cuts = [vpc.dp.shard_rows(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+# ----------------------------------------------------------------------------------------------- GPU, 2 ranks
+def _gpu_worker(rank, world, port, d, B, steps, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    vpc.dp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    params = O.init_params(d, L, seed=5)
+    m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
+    sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
+    m.to(dev)
+    vpc.dp.broadcast_parameters(m.flatten_parameters())
+    tr = vpc.FusedTrainer(m, world_size=world)
+    x, mask, mask_p, eq, ep = _inputs(B, d)
+    lo, hi = vpc.dp.shard_rows(B, rank, world)
+    losses = []
+    for i in range(steps):
+        tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eq[lo:hi].to(dev), ep[lo:hi].to(dev),
+                alpha=0.8, beta=0.9, epoch=i + 1, global_batch=B)
+        losses.append(tr.loss_value())
+    if rank == 0:
+        out.put((losses, m._flat.cpu().numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_fused_trainer_matches_single_process():
+    d, B, steps = 128, 512, 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, d, B, steps, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses2, flat2 = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    params = O.init_params(d, L, seed=5)
+    m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
+    sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
+    m.to(dev)
+    tr = vpc.FusedTrainer(m)
+    x, mask, mask_p, eq, ep = _inputs(B, d)
+    for i in range(steps):
+        tr.step(x.to(dev), mask.to(dev), mask_p.to(dev), eq.to(dev), ep.to(dev), alpha=0.8, beta=0.9, epoch=i + 1)
+        assert abs(tr.loss_value() - losses2[i]) <= 2e-6 * abs(losses2[i])
+    flat1 = m._flat.cpu().numpy()
+    assert np.max(np.abs(flat1 - flat2)) <= 2e-6 * np.max(np.abs(flat1))
