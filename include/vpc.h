@@ -64,18 +64,20 @@ int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 /* ---- encoder: Reg_VAE.encoder / vanilla_VAE.encoder, src/models/VAE.py:387-395, 1155-1163 -------- */
 
 /* For each pass p: h = MLP(x * mask[p]); mean[p], logvar[p] = chunk(h); if z[p]: z = mean + eps[p] *
- * exp(logvar / 2) (eps[p] NULL -> z = mean, the sample=False branch).  eps / z arrays may be NULL. */
+ * exp(logvar / 2) (eps[p] NULL -> z = mean, the sample=False branch).  eps / z arrays may be NULL.
+ * lat_pitch = row pitch in floats of mean / logvar: L (the reference's dense [B][L] tensors) or 16 (padded
+ * 16-byte aligned workspaces of the fused path, pad entries written as 0; z must then be NULL). */
 int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                    float* const* logvar, float* const* z, long B, int d, int L, void* stream);
+                    float* const* logvar, float* const* z, int lat_pitch, long B, int d, int L, void* stream);
 
 /* Autograd of the above (src/experiment_main/train.py:115): given d loss / d mean and d loss / d logvar
  * (with the reparameterisation path already folded in) accumulate the encoder weight gradients of all
  * passes into partial blocks [*nblocks_out][enc_part_floats].  x needs no gradient (layer-0 dgrad skipped). */
 int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* h1, const float* const* h2, const float* const* dmean,
-                    const float* const* dlogvar, float* partials, int* nblocks_out, long B, int d, int L,
-                    void* stream);
+                    const float* const* dlogvar, int lat_pitch, float* partials, int* nblocks_out, long B, int d,
+                    int L, void* stream);
 
 /* ---- decoder: Reg_VAE.decoder, src/models/VAE.py:397-401 ----------------------------------------- */
 
@@ -107,13 +109,14 @@ int vpc_loss_fwd_bwd(const float* x, int npass, const float* const* xhat, const 
 /* Fused training path: reparameterise + decoder forward + loss + backward seeds + decoder backward in one
  * pass (nothing of size B x d is written).  Outputs the TOTAL seeds on the encoder outputs
  * (dmean[p], dlogvar[p], reparameterisation path included), decoder partial blocks and loss partials
- * (term 7 unused).  Replaces VAE.py:389-392 (rsample), 397-401, 403-467 and their autograd. */
+ * (term 7 unused).  mean / logvar / eps / eps_ml / dmean / dlogvar are padded [B][16] workspaces (lat_pitch must
+ * be 16; pad entries of mean / logvar must be 0 as vpc_encoder_fwd writes them, pad entries of eps are ignored).  Replaces VAE.py:389-392 (rsample), 397-401, 403-467 and their autograd. */
 int vpc_decoder_fused(const float* x, const float* dec_img, int npass, const uint8_t* const* maskA,
                       const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* mean,
                       const float* const* logvar, const float* const* eps, const float* eps_ml, float bq, float bp,
                       float cr, float wml, float inv_B, float x_logvar, float* const* dmean,
-                      float* const* dlogvar, float* partials, double* loss_partials, int* nblocks_out, long B,
-                      int d, int L, void* stream);
+                      float* const* dlogvar, int lat_pitch, float* partials, double* loss_partials,
+                      int* nblocks_out, long B, int d, int L, void* stream);
 
 /* out9[0] = loss / B_global with the NLL constants of the B_local rows this rank processed (so that the
  * sum over data-parallel ranks is the loss of the concatenated batch), out9[1..8] = the 8 raw sums;

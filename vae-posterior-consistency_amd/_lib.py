@@ -38,14 +38,14 @@ _PROTOS = {
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
     "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P],
-    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, L_, I, I, P],
-    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, P, IP, L_, I, I, P],
+    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, L_, I, I, P],
+    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
     "vpc_decoder_bwd": [P, P, P, P, P, IP, L_, I, I, P],
     "vpc_loss_fwd_bwd": [P, I, PP, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, P, F, F, F, F, F, F, PP, PP, PP, P, I,
                          IP, L_, I, I, P],
-    "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, P, P,
-                          IP, L_, I, I, P],
+    "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, P,
+                          P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P],

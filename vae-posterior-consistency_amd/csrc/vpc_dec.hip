@@ -40,6 +40,7 @@ struct DecArgs {
     float bq, bp, cr, wml, inv_B, x_logvar;
     long B;
     int d, L, npass, ntiles;
+    int lp;   // row pitch of the [B][.] latent arrays: L (dense, API tensors) or 16 (padded workspaces)
     int dbg;  // ablation mask, only honoured by the diagnostic build (-DVPC_ABLATE); 0 in the product build
 };
 
@@ -50,7 +51,15 @@ struct DecArgs {
 // (measured on MI355X: 326 us without the region cuts, 252 us with them).
 #ifdef VPC_ABLATE
 #define VPC_DBG(bit) ((a.dbg & (bit)) != 0)
+// phase timing (diagnostic build only): accumulate s_memtime deltas per phase, printed by block 0 / thread 0
+#define VPC_STAMP(i)                                        \
+    do {                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        T[i] += t_ - tlast;                                 \
+        tlast = t_;                                         \
+    } while (0)
 #else
+#define VPC_STAMP(i) do {} while (0)
 __device__ __forceinline__ int opaque_zero() {
     int z;
     asm volatile("s_mov_b32 %0, 0" : "=s"(z));
@@ -58,6 +67,11 @@ __device__ __forceinline__ int opaque_zero() {
 }
 #define VPC_DBG(bit) ((opaque_zero() & (bit)) != 0)
 #endif
+// scheduling-region cut with no other effect (a never-taken branch around an empty asm)
+#define VPC_CUT()                                              \
+    do {                                                       \
+        if (VPC_DBG(0x4000)) asm volatile("s_nop 0");          \
+    } while (0)
 
 constexpr int DEC_CH = 64;  // batch rows per wgrad staging chunk = batch tile nb of all 4 waves
 
@@ -67,6 +81,10 @@ constexpr int DEC_CH = 64;  // batch rows per wgrad staging chunk = batch tile n
 template <int DT, bool VEC, int MODE>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VPC_ABLATE
+    unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int CH = DEC_CH, NB = DEC_NB;
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
     constexpr int I6 = (DT + 3) / 4;  // dW6 out tiles per wave (mt = w + 4i)
@@ -79,10 +97,28 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
     float* red = stB + H1P * CH;   // [DEC_WAVES][8]
     __syncthreads();
+    VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * w;
     const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
     constexpr float HL2PI = 0.91893853320467274f;
+
+    // latent arrays: 16-byte vector access when padded to 16 floats per row (pad entries are zero / ignored)
+    // (the fused mode always works on the padded workspaces, the API modes on dense [B][L] tensors)
+    constexpr bool PAD = (MODE == MODE_FUSED);
+    auto ld_lat = [&](const float* base, long r, bool rok) -> f32x4 {
+        if (PAD) return ld_tile<true>(base, r, 16, 4 * q, 16, rok);
+        return ld_tile<false>(base, r, a.L, 4 * q, a.L, rok);
+    };
+    auto st_lat = [&](float* base, long r, bool rok, f32x4 v) {
+        if (PAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (4 * q + j < a.L) ? v[j] : 0.f;
+            st_tile<true>(base, r, 16, 4 * q, 16, rok, v);
+        } else {
+            st_tile<false>(base, r, a.L, 4 * q, a.L, rok, v);
+        }
+    };
 
     f32x4 acc6[2][H1T], acc5[2][H2T], acc4 = zero4();
 #pragma unroll
@@ -112,16 +148,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
             for (int nb = 0; nb < NB; ++nb) {
                 epsfac[nb] = zero4(); dmu_kl[nb] = zero4(); dlv_kl[nb] = zero4();
                 if (a.z_in[p]) {
-                    z[nb][0] = ld_tile<false>(a.z_in[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                    z[nb][0] = ld_lat(a.z_in[p], row[nb], ok[nb]);
                     continue;
                 }
-                const f32x4 mu = ld_tile<false>(a.mean[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
-                const f32x4 lv = ld_tile<false>(a.logvar[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                const f32x4 mu = ld_lat(a.mean[p], row[nb], ok[nb]);
+                const f32x4 lv = ld_lat(a.logvar[p], row[nb], ok[nb]);
                 f32x4 e = zero4();
-                if (a.eps[p]) e = ld_tile<false>(a.eps[p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                if (a.eps[p]) {
+                    e = ld_lat(a.eps[p], row[nb], ok[nb]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float sig = expf(0.5f * lv[j]);
+                    const float sig = __expf(0.5f * lv[j]);
                     z[nb][0][j] = mu[j] + e[j] * sig;
                     epsfac[nb][j] = e[j] * 0.5f * sig;
                 }
@@ -132,8 +172,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     const bool two = a.npass == 2;
                     f32x4 mo = zero4(), lo = zero4();
                     if (two) {
-                        mo = ld_tile<false>(a.mean[1 - p], row[nb], a.L, 4 * q, a.L, ok[nb]);
-                        lo = ld_tile<false>(a.logvar[1 - p], row[nb], a.L, 4 * q, a.L, ok[nb]);
+                        mo = ld_lat(a.mean[1 - p], row[nb], ok[nb]);
+                        lo = ld_lat(a.logvar[1 - p], row[nb], ok[nb]);
                     }
                     const float b0 = (p == 0) ? a.bq : a.bp;
                     const float sgn = (p == 0) ? 1.f : -1.f;  // d KL(q||p) / d mu_q = -d / d mu_p
@@ -141,11 +181,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     float kl0 = 0.f, klr = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float elv = expf(lv[j]);
+                        const float elv = __expf(lv[j]);
                         kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
                         const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
                         const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                        const float diff = mq - mp, eip = expf(-lp), r = expf(lq - lp);
+                        const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
                         klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
                         const float dm = b0 * mu[j] + sgn * crr * diff * eip;
                         const float dl = b0 * 0.5f * (elv - 1.f) +
@@ -155,13 +195,15 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     }
                     if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
                     if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
-                        const f32x4 e3 = ld_tile<false>(a.eps_ml, row[nb], a.L, 4 * q, a.L, ok[nb]);
+                        f32x4 e3 = ld_lat(a.eps_ml, row[nb], ok[nb]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e3[j] = (4 * q + j < a.L) ? e3[j] : 0.f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool live = ok[nb] && 4 * q + j < a.L;
                             const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
                             const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                            const float sq = expf(0.5f * lq), eip = expf(-lp);
+                            const float sq = __expf(0.5f * lq), eip = __expf(-lp);
                             const float dlt = mq + e3[j] * sq - mp;
                             const float g = a.wml * dlt * eip * a.inv_B;
                             if (p == 0) {
@@ -176,6 +218,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     }
                 }
             }
+            VPC_STAMP(1);
             const bool skip_dec = (MODE == MODE_FUSED) && a.cA[p] == 0.f && a.cE[p] == 0.f;
             f32x4 dzt[NB];
 #pragma unroll
@@ -206,49 +249,79 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     for (int nb = 0; nb < NB; ++nb) g2[nb][mt] = relu4(acc[nb]);
                 }
                 launder(cc, qq);
+                VPC_STAMP(2);
                 f32x4 dpre[NB][DT];
                 float sa = 0.f, se = 0.f;
+                // Software pipeline over the DT output tiles: while the MFMAs of tile mt+1 run, the VALU work of
+                // tile mt (sigmoid, NLL terms, d/dxhat) is done, and the x / mask loads of tile mt+1 are in flight.
+                f32x4 pre_cur[NB] = {zero4(), zero4()};
+                f32x4 xv_cur[NB];
+                uint32_t ua_cur[NB], ub_cur[NB];
+                const bool hasB = (MODE == MODE_FUSED) && a.mB[p] != nullptr;
+                auto fetch = [&](int mt, f32x4 (&xv)[NB], uint32_t (&ua)[NB], uint32_t (&ub)[NB]) {
+                    const int f0 = 16 * mt + 4 * q;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        ua[nb] = 0u; ub[nb] = 0u;
+                        if (MODE == MODE_FUSED) {
+                            xv[nb] = ld_tile<VEC>(a.x, row[nb], a.d, f0, a.d, ok[nb]);
+                            ua[nb] = ld_mask_raw<VEC>(a.mA[p], row[nb], a.d, f0, a.d, ok[nb]);
+                            if (hasB) ub[nb] = ld_mask_raw<VEC>(a.mB[p], row[nb], a.d, f0, a.d, ok[nb]);
+                        } else if (MODE == MODE_BWD) {
+                            xv[nb] = ld_tile<VEC>(a.dxhat[p], row[nb], a.d, f0, a.d, ok[nb]);
+                        } else {
+                            xv[nb] = zero4();
+                        }
+                    }
+                };
+                fetch(0, xv_cur, ua_cur, ub_cur);
+                tile_fwd_nb<H1T, 128, NB>(W6, 0, g2, pre_cur, cc, qq);
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
-                    __builtin_amdgcn_sched_barrier(0);  // one output tile at a time: x / mask loads stay local
-                    f32x4 pre[NB] = {zero4(), zero4()};
-                    tile_fwd_nb<H1T, 128, NB>(W6, mt, g2, pre, cc, qq);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 pre_nxt[NB] = {zero4(), zero4()};
+                    f32x4 xv_nxt[NB];
+                    uint32_t ua_nxt[NB], ub_nxt[NB];
+                    if (mt + 1 < DT) {
+                        fetch(mt + 1, xv_nxt, ua_nxt, ub_nxt);
+                        tile_fwd_nb<H1T, 128, NB>(W6, mt + 1, g2, pre_nxt, cc, qq);
+                    }
                     const int f0 = 16 * mt + 4 * q;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         f32x4 xh;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) xh[j] = 1.f / (1.f + expf(-pre[nb][j]));
+                        for (int j = 0; j < 4; ++j) xh[j] = fast_sigmoid(pre_cur[nb][j]);
                         if (MODE == MODE_FWD) {
                             st_tile<VEC>(a.xhat[p], row[nb], a.d, f0, a.d, ok[nb], xh);
                             continue;
                         }
                         f32x4 dxh;
                         if (MODE == MODE_FUSED && VPC_DBG(8)) {
-                            dxh = pre[nb] * a.inv_B;
+                            dxh = pre_cur[nb] * a.inv_B;
                         } else if (MODE == MODE_FUSED) {
-                            const f32x4 xv = ld_tile<VEC>(a.x, row[nb], a.d, f0, a.d, ok[nb]);
-                            const f32x4 mA = ld_mask<VEC>(a.mA[p], row[nb], a.d, f0, a.d, ok[nb]);
-                            f32x4 mE = zero4();
-                            if (a.mB[p]) {
-                                const f32x4 mB = ld_mask<VEC>(a.mB[p], row[nb], a.d, f0, a.d, ok[nb]);
-                                mE = mA * (1.f - mB);
-                            }
+                            const f32x4 mA = mask_to_f32(ua_cur[nb]);
+                            const f32x4 mE = hasB ? mA * (1.f - mask_to_f32(ub_cur[nb])) : zero4();
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float diff = xh[j] - xv[j];
+                                const float diff = xh[j] - xv_cur[nb][j];
                                 const float t = half_lv + 0.5f * diff * diff * inv_s2;
                                 sa += mA[j] * t;
                                 se += mE[j] * t;
                                 dxh[j] = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
                             }
                         } else {
-                            dxh = ld_tile<VEC>(a.dxhat[p], row[nb], a.d, f0, a.d, ok[nb]);
+                            dxh = xv_cur[nb];
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) dpre[nb][mt][j] = dxh[j] * xh[j] * (1.f - xh[j]);
                     }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        pre_cur[nb] = pre_nxt[nb]; xv_cur[nb] = xv_nxt[nb]; ua_cur[nb] = ua_nxt[nb]; ub_cur[nb] = ub_nxt[nb];
+                    }
                 }
+                VPC_STAMP(3);
                 if (MODE != MODE_FWD) {
                     if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
                     uint32_t gm2[NB], gm1[NB];
@@ -272,18 +345,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fa[I6];
 #pragma unroll
                             for (int i = 0; i < I6; ++i) fa[i] = stage_frag<CH>(stA, (w + 4 * i) % DT, s, cc, qq);
+                            f32x4 fb[H1T];
 #pragma unroll
-                            for (int nt = 0; nt < H1T; ++nt) {
-                                const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
+                            for (int nt = 0; nt < H1T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
+#pragma unroll
+                            for (int nt = 0; nt < H1T; ++nt)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                                     for (int i = 0; i < I6; ++i)
-                                        if (w + 4 * i < DT) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[j], acc6[i][nt]);
-                            }
+                                        if (w + 4 * i < DT) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[nt][j], acc6[i][nt]);
                         }
                     }
                     // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
+                    VPC_STAMP(4);
                     launder(cc, qq);
                     f32x4 dg2[NB][H1T];
 #pragma unroll
@@ -295,6 +370,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         for (int nb = 0; nb < NB; ++nb) dg2[nb][mt] = gate_bits(acc[nb], gm2[nb], mt);
                     }
                     // ---------------- dW5~ += dg2 * g1^T   (owner: wave w -> out tiles w, w+4 (<7); 4 in tiles)
+                    VPC_STAMP(5);
                     launder(cc, qq);
 #pragma unroll
                     for (int ch = 0; ch < NB; ++ch) {
@@ -312,18 +388,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fa[2];
                             fa[0] = stage_frag<CH>(stA, w, s, cc, qq);
                             fa[1] = stage_frag<CH>(stA, (w + 4) % H1T, s, cc, qq);
+                            f32x4 fb[H2T];
 #pragma unroll
-                            for (int nt = 0; nt < H2T; ++nt) {
-                                const f32x4 fb = stage_frag<CH>(stB, nt, s, cc, qq);
+                            for (int nt = 0; nt < H2T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
+#pragma unroll
+                            for (int nt = 0; nt < H2T; ++nt)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    acc5[0][nt] = VPC_MFMA(fa[0][j], fb[j], acc5[0][nt]);
-                                    if (w + 4 < H1T) acc5[1][nt] = VPC_MFMA(fa[1][j], fb[j], acc5[1][nt]);
+                                    acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
+                                    if (w + 4 < H1T) acc5[1][nt] = VPC_MFMA(fa[1][j], fb[nt][j], acc5[1][nt]);
                                 }
-                            }
                         }
                     }
                     // ---------------- dg1 = relu'(g1) * (W5~^T dg2)
+                    VPC_STAMP(6);
                     launder(cc, qq);
                     f32x4 dg1[NB][H2T];
 #pragma unroll
@@ -335,6 +413,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         for (int nb = 0; nb < NB; ++nb) dg1[nb][mt] = gate_bits(acc[nb], gm1[nb], mt);
                     }
                     // ---------------- dW4~ += dg1 * z^T   (owner: wave w -> out tile w)
+                    VPC_STAMP(7);
                     launder(cc, qq);
 #pragma unroll
                     for (int ch = 0; ch < NB; ++ch) {
@@ -356,18 +435,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     tile_T_nb<H2T, S4, NB>(W4, 0, dg1, dzt, cc, qq);
                 }
             }
+            VPC_STAMP(8);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if (MODE == MODE_FUSED) {
                     // total seeds on the encoder outputs: KL part + reparameterisation path
-                    st_tile<false>(a.dmean[p], row[nb], a.L, 4 * q, a.L, ok[nb], dmu_kl[nb] + dzt[nb]);
-                    st_tile<false>(a.dlogvar[p], row[nb], a.L, 4 * q, a.L, ok[nb], dlv_kl[nb] + dzt[nb] * epsfac[nb]);
+                    st_lat(a.dmean[p], row[nb], ok[nb], dmu_kl[nb] + dzt[nb]);
+                    st_lat(a.dlogvar[p], row[nb], ok[nb], dlv_kl[nb] + dzt[nb] * epsfac[nb]);
                 } else if (MODE == MODE_BWD) {
-                    st_tile<false>(a.dz[p], row[nb], a.L, 4 * q, a.L, ok[nb], dzt[nb]);
+                    st_lat(a.dz[p], row[nb], ok[nb], dzt[nb]);
                 }
             }
         }
     }
+    VPC_STAMP(9);
     if (MODE == MODE_FWD) return;
     float* part = a.part + (long)blockIdx.x * DEC_PART + (long)w * DEC_GREGS * 64 + lane;
 #pragma unroll
@@ -398,6 +479,12 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
             a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
         }
     }
+#ifdef VPC_ABLATE
+    VPC_STAMP(10);
+    if (VPC_DBG(64) && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0)
+        printf("blk %d wave %d ticks(100MHz): prologue %llu latent %llu g1g2 %llu out %llu w6 %llu dg2 %llu w5 %llu dg1 %llu "
+               "w4+dz %llu store %llu | tail9 %llu epi %llu\n", blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9] , T[9], T[10]);
+#endif
 }
 
 static size_t dec_lds(int DT, int mode) {
@@ -445,7 +532,7 @@ extern "C" int vpc_decoder_fwd(const float* z, const float* dec_img, float* xhat
     if (!z || !dec_img || !xhat) return VPC_ERR_ARG;
     if (int e = check_common(B, d, L, 1)) return e;
     DecArgs a{};
-    a.img = dec_img; a.z_in[0] = z; a.xhat[0] = xhat; a.B = B; a.d = d; a.L = L; a.npass = 1;
+    a.img = dec_img; a.z_in[0] = z; a.xhat[0] = xhat; a.B = B; a.d = d; a.L = L; a.npass = 1; a.lp = L;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
     const bool vec = (d % 4 == 0) && aligned16(xhat);
     return dispatch<MODE_FWD>(a, vec, (hipStream_t)stream);
@@ -457,7 +544,7 @@ extern "C" int vpc_decoder_bwd(const float* z, const float* dxhat, const float* 
     if (int e = check_common(B, d, L, 1)) return e;
     DecArgs a{};
     a.img = dec_img; a.z_in[0] = z; a.dxhat[0] = dxhat; a.dz[0] = dz; a.part = partials;
-    a.B = B; a.d = d; a.L = L; a.npass = 1;
+    a.B = B; a.d = d; a.L = L; a.npass = 1; a.lp = L;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
     if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
     const bool vec = (d % 4 == 0) && aligned16(dxhat);
@@ -468,8 +555,9 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
                                  const uint8_t* const* maskB, const float* cA, const float* cE,
                                  const float* const* mean, const float* const* logvar, const float* const* eps,
                                  const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B,
-                                 float x_logvar, float* const* dmean, float* const* dlogvar, float* partials,
-                                 double* loss_partials, int* nblocks_out, long B, int d, int L, void* stream) {
+                                 float x_logvar, float* const* dmean, float* const* dlogvar, int lat_pitch,
+                                 float* partials, double* loss_partials, int* nblocks_out, long B, int d, int L,
+                                 void* stream) {
     if (!x || !dec_img || !maskA || !cA || !cE || !mean || !logvar || !dmean || !dlogvar || !partials ||
         !loss_partials)
         return VPC_ERR_ARG;
@@ -477,7 +565,8 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     DecArgs a{};
     a.x = x; a.img = dec_img; a.part = partials; a.loss_part = loss_partials; a.eps_ml = eps_ml;
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
-    a.B = B; a.d = d; a.L = L; a.npass = npass;
+    if (lat_pitch != 16) return VPC_ERR_ARG;  // the fused kernel works on padded [B][16] latent workspaces only
+    a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);

@@ -22,6 +22,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VPC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// sigmoid through v_exp_f32 / v_rcp_f32 (<= 2 ulp each; |rel err| < 1e-6 for |x| < 16).  The IEEE expf + divide
+// expansion costs ~45 VALU instructions per element, this one ~6.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
@@ -53,14 +56,17 @@ __device__ __forceinline__ void tile_fwd_nb(const float* W, int mt, const f32x4 
                                             int m, int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
     const float* rowp = W + (16 * mt + m) * S;
+    // all A fragments of the tile are requested before the first MFMA: with one wave per SIMD nothing else
+    // hides the LDS latency, and a read issued right before its use costs ~100 cycles per 8 MFMAs
+    f32x4 a[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
+    for (int kt = 0; kt < KT; ++kt) a[kt] = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[j], in[nb][kt][j], acc[nb]);
-    }
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
 }
 template <int KT, int S, int NB>
 __device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB], int m,
@@ -68,16 +74,20 @@ __device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&
     constexpr int MASK = (S / 4 - 1) & 15;
     const int col = 16 * mt + m;
     const int cs = col >> 2, cl = col & 3;
+    float a[KT][4];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            const float a = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a, in[nb][kt][j], acc[nb]);
+            a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
         }
-    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
 }
 
 // out tile mt of  W[out][in] * in   (A fragment: one ds_read_b128 per 4 MFMAs)
@@ -181,6 +191,30 @@ __device__ __forceinline__ f32x4 ld_mask(const uint8_t* base, long row, int ld, 
         }
     }
     return v;
+}
+
+// raw 4 mask bytes (one per feature) as a u32; out-of-range bytes read as 0
+template <bool VEC>
+__device__ __forceinline__ uint32_t ld_mask_raw(const uint8_t* base, long row, int ld, int f0, int nvalid, bool row_ok) {
+    const long off = row * ld + f0;
+    uint32_t u = 0;
+    if (VEC) {
+        const bool ok = row_ok && f0 + 3 < nvalid;
+        u = *reinterpret_cast<const uint32_t*>(base + (ok ? off : 0));
+        u = ok ? u : 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row_ok && f0 + j < nvalid;
+            const uint32_t t = base[ok ? off + j : 0];
+            u |= (ok ? t : 0u) << (8 * j);
+        }
+    }
+    return u;
+}
+__device__ __forceinline__ f32x4 mask_to_f32(uint32_t u) {
+    return f32x4{(u & 0xffu) ? 1.f : 0.f, (u & 0xff00u) ? 1.f : 0.f, (u & 0xff0000u) ? 1.f : 0.f,
+                 (u & 0xff000000u) ? 1.f : 0.f};
 }
 
 // copy a packed image global -> LDS (16-byte granules; n is a multiple of 4).  8 loads are kept in flight per

@@ -19,7 +19,7 @@ struct EncFwdArgs {
     float* logvar[2];
     float* z[2];
     long B;
-    int d, L, npass, ntiles;
+    int d, L, npass, ntiles, lp;
 };
 
 template <int DT, bool VEC>
@@ -68,8 +68,13 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             }
             const f32x4 mu = tile_fwd<H2T, 64>(W3, 0, h2, zero4(), cc, qq);
             const f32x4 lv = tile_fwd<H2T, 64>(W3, 1, h2, zero4(), cc, qq);
-            st_tile<false>(a.mean[p], row, a.L, 4 * q, a.L, ok, mu);
-            st_tile<false>(a.logvar[p], row, a.L, 4 * q, a.L, ok, lv);
+            if (a.lp == 16) {  // padded workspaces: rows are 16 floats, features >= L are exact zeros
+                st_tile<true>(a.mean[p], row, 16, 4 * q, 16, ok, mu);
+                st_tile<true>(a.logvar[p], row, 16, 4 * q, 16, ok, lv);
+            } else {
+                st_tile<false>(a.mean[p], row, a.L, 4 * q, a.L, ok, mu);
+                st_tile<false>(a.logvar[p], row, a.L, 4 * q, a.L, ok, lv);
+            }
             if (a.z[p]) {
                 f32x4 z = mu;
                 if (a.eps[p]) {
@@ -93,7 +98,7 @@ struct EncBwdArgs {
     const float* dlogvar[2];
     float* part;
     long B;
-    int d, L, npass, ntiles;
+    int d, L, npass, ntiles, lp;
 };
 
 constexpr int ENC_CH = 64;  // batch rows per wgrad staging chunk
@@ -130,8 +135,13 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             int cc = c, qq = q;
             launder(cc, qq);
             f32x4 dml[2];
-            dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
-            dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
+            if (a.lp == 16) {
+                dml[0] = ld_tile<true>(a.dmean[p], row, 16, 4 * q, 16, ok);
+                dml[1] = ld_tile<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok);
+            } else {
+                dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
+                dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
+            }
             f32x4 h2[H2T];
 #pragma unroll
             for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
@@ -280,12 +290,15 @@ using namespace vpc;
 
 extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                               float* const* logvar, float* const* z, long B, int d, int L, void* stream) {
+                               float* const* logvar, float* const* z, int lat_pitch, long B, int d, int L,
+                               void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !mean || !logvar) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
     if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
+    if (lat_pitch != L && z) return VPC_ERR_ARG;  // z is only produced in the dense [B][L] layout
     EncFwdArgs a{};
-    a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass;
+    a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
@@ -309,13 +322,14 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
 
 extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* h1, const float* const* h2, const float* const* dmean,
-                               const float* const* dlogvar, float* partials, int* nblocks_out, long B, int d,
-                               int L, void* stream) {
+                               const float* const* dlogvar, int lat_pitch, float* partials, int* nblocks_out,
+                               long B, int d, int L, void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !dmean || !dlogvar || !partials) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
     if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     EncBwdArgs a{};
-    a.x = x; a.img = enc_img; a.part = partials; a.B = B; a.d = d; a.L = L; a.npass = npass;
+    a.x = x; a.img = enc_img; a.part = partials; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {

@@ -27,6 +27,8 @@ from . import ops
 from .models import MAX_EPOCH, Reg_VAE, vanilla_VAE
 from .ops import H1P, H2P, as_mask_u8
 
+LP = 16  # row pitch of the padded latent workspaces
+
 
 class FusedTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
@@ -73,11 +75,12 @@ class FusedTrainer:
         np_ = 1 if self.vanilla else 2
         self.h1 = [torch.empty(B, H1P, device=dev) for _ in range(np_)]
         self.h2 = [torch.empty(B, H2P, device=dev) for _ in range(np_)]
-        self.mean = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
-        self.logvar = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
-        self.dmean = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
-        self.dlogvar = [torch.empty(B, Ld, device=dev) for _ in range(np_)]
-        self.eps_buf = torch.empty(3, B, Ld, device=dev)
+        # latent statistics live in padded [B][16] workspaces (16-byte vector access in the kernels)
+        self.mean = [torch.empty(B, LP, device=dev) for _ in range(np_)]
+        self.logvar = [torch.empty(B, LP, device=dev) for _ in range(np_)]
+        self.dmean = [torch.empty(B, LP, device=dev) for _ in range(np_)]
+        self.dlogvar = [torch.empty(B, LP, device=dev) for _ in range(np_)]
+        self.eps_buf = torch.empty(3, B, LP, device=dev)
         self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
         self._ws_B = B
 
@@ -134,20 +137,26 @@ class FusedTrainer:
         if eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None):
             ops.fill_normal(self.eps_buf, self.seed, self.rng_offset)
             self.rng_offset += (self.eps_buf.numel() + 3) // 4
-        eq = self.eps_buf[0] if eps_q is None else ops._f32c(eps_q)
-        ep = (self.eps_buf[1] if eps_p is None else ops._f32c(eps_p)) if two else None
-        eml = (self.eps_buf[2] if eps_ml is None else ops._f32c(eps_ml)) if need_ml else None
+        if eps_q is not None:  # injected draws (parity tests) arrive dense [B][L]; pad entries are ignored
+            self.eps_buf[0, :, :Ld].copy_(eps_q)
+        if two and eps_p is not None:
+            self.eps_buf[1, :, :Ld].copy_(eps_p)
+        if need_ml and eps_ml is not None:
+            self.eps_buf[2, :, :Ld].copy_(eps_ml)
+        eq = self.eps_buf[0]
+        ep = self.eps_buf[1] if two else None
+        eml = self.eps_buf[2] if need_ml else None
         masks = [mask, mask_p] if two else [mask]
         epss = [eq, ep] if two else [eq]
         # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
         self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
-                    None, d, Ld)
+                    None, d, Ld, LP)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
         nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
                           self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
-                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld)
+                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
-                          self.dlogvar, self.partE, d, Ld)
+                          self.dlogvar, self.partE, d, Ld, LP)
         # ---- flat gradient + loss terms
         ops.reduce_partials(self.partE, nbE, lay.enc_part, self.gidx[:lay.n_enc], self.grad[:lay.n_enc])
         ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], self.grad[lay.n_enc:])

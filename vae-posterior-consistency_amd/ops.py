@@ -47,21 +47,21 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
                               int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
 
 
-def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld):
+def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None):
     n = len(masks)
     B = x.shape[0]
     check(lib().vpc_encoder_fwd(ptr(x), ptr(enc_img), n, ptr_array(masks),
                                 ptr_array(eps) if eps is not None else None, ptr_array(h1), ptr_array(h2),
-                                ptr_array(mean), ptr_array(logvar), ptr_array(z) if z is not None else None, B, d, Ld,
-                                stream_ptr()), "vpc_encoder_fwd")
+                                ptr_array(mean), ptr_array(logvar), ptr_array(z) if z is not None else None,
+                                lat_pitch or Ld, B, d, Ld, stream_ptr()), "vpc_encoder_fwd")
 
 
-def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld):
+def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld, lat_pitch=None):
     n = len(masks)
     nb = C.c_int(0)
     check(lib().vpc_encoder_bwd(ptr(x), ptr(enc_img), n, ptr_array(masks), ptr_array(h1), ptr_array(h2),
-                                ptr_array(dmean), ptr_array(dlogvar), ptr(partials), C.byref(nb), x.shape[0], d, Ld,
-                                stream_ptr()), "vpc_encoder_bwd")
+                                ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, ptr(partials), C.byref(nb),
+                                x.shape[0], d, Ld, stream_ptr()), "vpc_encoder_bwd")
     return nb.value
 
 
@@ -90,13 +90,13 @@ def loss_fwd_bwd(x, xhat, maskA, maskB, cA, cE, mean, logvar, eps_ml, bq, bp, cr
 
 
 def decoder_fused(x, dec_img, maskA, maskB, cA, cE, mean, logvar, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, dmean,
-                  dlogvar, partials, loss_part, d, Ld):
+                  dlogvar, partials, loss_part, d, Ld, lat_pitch=None):
     n = len(maskA)
     nb = C.c_int(0)
     check(lib().vpc_decoder_fused(ptr(x), ptr(dec_img), n, ptr_array(maskA), ptr_array(maskB), farray(cA), farray(cE),
                                   ptr_array(mean), ptr_array(logvar), ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml,
-                                  inv_B, x_logvar, ptr_array(dmean), ptr_array(dlogvar), ptr(partials), ptr(loss_part),
-                                  C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_decoder_fused")
+                                  inv_B, x_logvar, ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, ptr(partials),
+                                  ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_decoder_fused")
     return nb.value
 
 
