@@ -11,4 +11,6 @@
 namespace vpc {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 int num_cus();  // CUs of the current device (cached)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size); false on a HIP error
+bool lds_attr_done(const void* kern, size_t lds);
 }  // namespace vpc

@@ -496,9 +496,7 @@ static size_t dec_lds(int DT, int mode) {
 
 template <typename K>
 static int launch(K kern, const DecArgs& args, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return VPC_ERR_HIP;
+    if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;
     const int grid = args.ntiles < num_cus() ? args.ntiles : num_cus();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC_THREADS), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;

@@ -90,18 +90,21 @@ __device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&
             for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
 }
 
-// out tile mt of  W[out][in] * in   (A fragment: one ds_read_b128 per 4 MFMAs)
+// out tile mt of  W[out][in] * in   (A fragments: one ds_read_b128 per 4 MFMAs, all requested up front)
 template <int KT, int S>
 __device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
                                           int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
     const float* rowp = W + (16 * mt + m) * S;
+    f32x4 a[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) a[kt] = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ m));
-        acc = VPC_MFMA(a[0], in[kt][0], acc);
-        acc = VPC_MFMA(a[1], in[kt][1], acc);
-        acc = VPC_MFMA(a[2], in[kt][2], acc);
-        acc = VPC_MFMA(a[3], in[kt][3], acc);
+        acc = VPC_MFMA(a[kt][0], in[kt][0], acc);
+        acc = VPC_MFMA(a[kt][1], in[kt][1], acc);
+        acc = VPC_MFMA(a[kt][2], in[kt][2], acc);
+        acc = VPC_MFMA(a[kt][3], in[kt][3], acc);
     }
     return acc;
 }
@@ -110,17 +113,21 @@ __device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&
 template <int KT, int S>
 __device__ __forceinline__ f32x4 tile_T(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
                                         int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
     const int col = 16 * mt + m;
     const int cs = col >> 2, cl = col & 3;
+    float a[KT][4];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;  // row & 15
-            const float a = W[(16 * kt + r) * S + (((cs ^ r) << 2) | cl)];
-            acc = VPC_MFMA(a, in[kt][j], acc);
+            a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
         }
-    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(a[kt][j], in[kt][j], acc);
     return acc;
 }
 

@@ -8,6 +8,17 @@
 
 namespace vpc {
 
+#ifdef VPC_ABLATE
+#define VPC_STAMP(i)                                        \
+    do {                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        T[i] += t_ - tlast;                                 \
+        tlast = t_;                                         \
+    } while (0)
+#else
+#define VPC_STAMP(i) do {} while (0)
+#endif
+
 struct EncFwdArgs {
     const float* x;
     const float* img;
@@ -25,10 +36,15 @@ struct EncFwdArgs {
 template <int DT, bool VEC>
 __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VPC_ABLATE
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int S1 = s_for_tiles(DT);
     const EncImg im(DT);
     load_image(lds, a.img, im.total);
     __syncthreads();
+    VPC_STAMP(0);
     const float* W1 = lds + im.oW1;
     const float* b1 = lds + im.ob1;
     const float* W2 = lds + im.oW2;
@@ -51,6 +67,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                 const f32x4 mk = ld_mask<VEC>(a.mask[p], row, a.d, 16 * t + 4 * q, a.d, ok);
                 xin[t] = xv * mk;  // x.float() * mask  (VAE.py:388)
             }
+            VPC_STAMP(1);
             f32x4 h1[H1T];
 #pragma unroll
             for (int mt = 0; mt < H1T; ++mt) {
@@ -59,6 +76,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                 h1[mt] = relu4(acc);
                 st_tile<true>(a.h1[p], row, H1P, 16 * mt + 4 * q, H1P, ok, h1[mt]);
             }
+            VPC_STAMP(2);
             launder(cc, qq);
             f32x4 h2[H2T];
 #pragma unroll
@@ -66,6 +84,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                 h2[mt] = relu4(tile_fwd<H1T, 128>(W2, mt, h1, zero4(), cc, qq));
                 st_tile<true>(a.h2[p], row, H2P, 16 * mt + 4 * q, H2P, ok, h2[mt]);
             }
+            VPC_STAMP(3);
             const f32x4 mu = tile_fwd<H2T, 64>(W3, 0, h2, zero4(), cc, qq);
             const f32x4 lv = tile_fwd<H2T, 64>(W3, 1, h2, zero4(), cc, qq);
             if (a.lp == 16) {  // padded workspaces: rows are 16 floats, features >= L are exact zeros
@@ -84,8 +103,14 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                 }
                 st_tile<false>(a.z[p], row, a.L, 4 * q, a.L, ok, z);
             }
+            VPC_STAMP(4);
         }
     }
+#ifdef VPC_ABLATE
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2)
+        printf("enc_fwd blk %d wave %d cycles: prologue %llu loadx %llu L1 %llu L2 %llu L3+st %llu\n", blockIdx.x,
+               (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4]);
+#endif
 }
 
 struct EncBwdArgs {
@@ -276,9 +301,7 @@ static size_t enc_bwd_lds(int DT) {
 
 template <typename K, typename A>
 static int launch(K kern, const A& args, int ntiles, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return VPC_ERR_HIP;
+    if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;
     const int grid = ntiles < num_cus() ? ntiles : num_cus();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;

@@ -6,6 +6,8 @@
 #include "vpc_abi_internal.h"
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace vpc {
 
@@ -19,6 +21,17 @@ int num_cus() {
         n = v;
     }
     return n;
+}
+
+bool lds_attr_done(const void* kern, size_t lds) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> seen;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = seen.find(kern);
+    if (it != seen.end() && it->second >= lds) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    seen[kern] = lds;
+    return true;
 }
 
 // packed row of encoder layer 3: mean rows -> tile 0, logvar rows -> tile 1

@@ -61,6 +61,8 @@ class FusedTrainer:
         self.pidx, self.gidx = self.lay.device_tables(self.dev)
         self._ws_B = None
         self.timers = None  # bench.py sets this to {} to collect per-kernel HIP event pairs
+        self.timer_every = 8  # ... on every 8th step only: an event pair costs ~5 us of GPU idle time per kernel
+        self._timer_tick = 0
         # make trainable tensors' .grad views of the flat gradient, so state is inspectable like torch's
         off = 0
         for p in model.trainable():
@@ -86,7 +88,7 @@ class FusedTrainer:
 
     def _timed(self, name, fn, *args):
         """Run one launch; with timers enabled bracket it with events on the launch stream."""
-        if self.timers is None:
+        if self.timers is None or self._timer_tick % self.timer_every:
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -116,6 +118,7 @@ class FusedTrainer:
         mask_p / eps_* are drawn on the device unless injected (parity tests).  Returns nothing: the loss of
         this step is in `self.out9[0]` (device), the running total in `self.accum` (train.py:117)."""
         L.require_cuda(x)
+        self._timer_tick += 1
         lay, m = self.lay, self.model
         B, d, Ld = x.shape[0], lay.d, lay.L
         x = ops._f32c(x)
