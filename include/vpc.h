@@ -125,12 +125,24 @@ int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float
                       float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
                       void* stream);
 
+/* vpc_reduce_partials (encoder) + vpc_reduce_partials (decoder) + vpc_loss_finalize in ONE launch: the whole
+ * post-backward reduction of the fused step.  grad_out[0, n_enc) from the encoder blocks, [n_enc, n) from the
+ * decoder blocks (grad_idx as returned by vpc_build_indices), out9 / accum as vpc_loss_finalize. */
+int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
+                    int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                    const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq, float bp,
+                    float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum, void* stream);
+
 /* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
 
 /* mask_out = mask_in AND (U < keep_prob): create_missing_uci(shape, rate) * mask with keep_prob = 1 - rate/100
  * (src/utils/utils.py:36-39, src/experiment_main/train.py:53-55).  mask_in NULL = all ones. */
 int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob, unsigned long long seed,
                   unsigned long long offset, void* stream);
+
+/* vpc_draw_mask + vpc_fill_normal in one launch (the two per-step draws of the fused step). */
+int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out, long n_eps,
+                  unsigned long long seed, unsigned long long offset_mask, unsigned long long offset_eps, void* stream);
 
 /* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392). */
 int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);

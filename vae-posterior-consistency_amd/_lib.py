@@ -47,7 +47,9 @@ _PROTOS = {
     "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, P,
                           P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
+    "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
+    "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P],
 }
 

@@ -48,12 +48,11 @@ __global__ void pack_kernel(const float* __restrict__ flat, const int* __restric
 // out[i] = scale * sum_b part[b * stride + idx[i]].  A 256-thread block handles 32 parameters x 8 block
 // groups (thread (pi, bg) sums blocks bg, bg+8, ...), then the 8 group sums are added in a fixed order:
 // bitwise reproducible, and 8x more loads in flight than one thread per parameter.
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
-                                                     const int* __restrict__ idx, float* __restrict__ out, int n,
-                                                     float scale) {
-    __shared__ float sh[8][32];
+__device__ __forceinline__ void reduce_body(const float* __restrict__ part, int nblocks, long stride,
+                                            const int* __restrict__ idx, float* __restrict__ out, int n, float scale,
+                                            int blk, float (*sh)[32]) {
     const int pi = threadIdx.x & 31, bg = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + pi;
+    const int i = blk * 32 + pi;
     float s0 = 0.f, s1 = 0.f;
     if (i < n) {
         const float* p = part + idx[i];
@@ -72,6 +71,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
         for (int k = 1; k < 8; ++k) t += sh[k][pi];
         out[i] = scale * t;
     }
+}
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
+                                                     const int* __restrict__ idx, float* __restrict__ out, int n,
+                                                     float scale) {
+    __shared__ float sh[8][32];
+    reduce_body(part, nblocks, stride, idx, out, n, scale, blockIdx.x, sh);
 }
 
 // torch.optim.Adam (no weight decay / amsgrad), src/experiment_main/train.py:21,116; optional re-pack
@@ -93,12 +98,13 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
 
 // loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums;
 // accum += loss.  256 threads: thread (term, g) sums blocks g, g+32, ...; fixed-order combine.
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ lp, int nblocks, float cA0,
-                                                            float cE0, float cA1, float bq, float bp, float cr,
-                                                            float wml, double nll_const, double inv_B,
-                                                            float* __restrict__ out, float* __restrict__ accum) {
-    __shared__ double sh[32][LOSS_TERMS];
-    __shared__ double s[LOSS_TERMS];
+struct LossCoef {
+    float cA0, cE0, cA1, bq, bp, cr, wml;
+    double nll_const, inv_B;
+};
+__device__ __forceinline__ void finalize_body(const double* __restrict__ lp, int nblocks, const LossCoef& k,
+                                              float* __restrict__ out, float* __restrict__ accum,
+                                              double (*sh)[LOSS_TERMS], double* s) {
     const int term = threadIdx.x & 7, g = threadIdx.x >> 3;
     double t = 0.0;
     for (int b = g; b < nblocks; b += 32) t += lp[(long)b * LOSS_TERMS + term];
@@ -106,17 +112,41 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __rest
     __syncthreads();
     if (threadIdx.x < LOSS_TERMS) {
         double u = 0.0;
-        for (int k = 0; k < 32; ++k) u += sh[k][threadIdx.x];
+        for (int j = 0; j < 32; ++j) u += sh[j][threadIdx.x];
         s[threadIdx.x] = u;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double loss = cA0 * (s[0] + nll_const) + cE0 * (s[1] + nll_const) + cA1 * (s[2] + nll_const) +
-                            bq * s[3] + bp * s[4] + cr * s[5] - wml * s[6];
-        out[0] = (float)(loss * inv_B);
+        const double loss = k.cA0 * (s[0] + k.nll_const) + k.cE0 * (s[1] + k.nll_const) + k.cA1 * (s[2] + k.nll_const) +
+                            k.bq * s[3] + k.bp * s[4] + k.cr * s[5] - k.wml * s[6];
+        out[0] = (float)(loss * k.inv_B);
         for (int i = 0; i < LOSS_TERMS; ++i) out[1 + i] = (float)s[i];
-        if (accum) accum[0] += (float)(loss * inv_B);
+        if (accum) accum[0] += (float)(loss * k.inv_B);
     }
+}
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ lp, int nblocks, LossCoef k,
+                                                            float* __restrict__ out, float* __restrict__ accum) {
+    __shared__ double sh[32][LOSS_TERMS];
+    __shared__ double s[LOSS_TERMS];
+    finalize_body(lp, nblocks, k, out, accum, sh, s);
+}
+
+// one launch for the whole post-backward reduction of the fused step: encoder partial blocks -> grad[0, n_enc),
+// decoder partial blocks -> grad[n_enc, n), loss partials -> out9 (+ accum); the last block does the loss
+__global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restrict__ partE, int nbE, long strideE,
+                                                          const float* __restrict__ partD, int nbD, long strideD,
+                                                          const int* __restrict__ idx, float* __restrict__ grad,
+                                                          int n_enc, int n, const double* __restrict__ lp, int nbL,
+                                                          LossCoef k, float* __restrict__ out9,
+                                                          float* __restrict__ accum) {
+    __shared__ float shf[8][32];
+    __shared__ double shd[32][LOSS_TERMS];
+    __shared__ double s[LOSS_TERMS];
+    const int gE = (n_enc + 31) / 32, gD = (n - n_enc + 31) / 32;
+    const int b = blockIdx.x;
+    if (b < gE) reduce_body(partE, nbE, strideE, idx, grad, n_enc, 1.f, b, shf);
+    else if (b < gE + gD) reduce_body(partD, nbD, strideD, idx + n_enc, grad + n_enc, n - n_enc, 1.f, b - gE, shf);
+    else finalize_body(lp, nbL, k, out9, accum, shd, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,9 +278,8 @@ __device__ __forceinline__ U4 philox(uint64_t ctr, uint32_t stream, uint64_t see
 __device__ __forceinline__ float u01(uint32_t u) { return ((u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // mask_out = mask_in & (U < keep_prob)   (create_missing_uci * mask, utils.py:36-39 + train.py:54-55)
-__global__ void draw_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
-                                 float keep_prob, uint64_t seed, uint64_t offset) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 bytes
+__device__ __forceinline__ void draw_mask_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
+                                               float keep_prob, uint64_t seed, uint64_t offset, long g) {
     const long i0 = g * 4;
     if (i0 >= n) return;
     const U4 r = philox((uint64_t)g + offset, 0u, seed);
@@ -268,8 +297,13 @@ __global__ void draw_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __rest
     }
 }
 
-__global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void draw_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
+                                 float keep_prob, uint64_t seed, uint64_t offset) {
+    draw_mask_body(in, out, n, keep_prob, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void fill_normal_body(float* __restrict__ out, long n, uint64_t seed, uint64_t offset,
+                                                 long g) {
     const long i0 = g * 4;
     if (i0 >= n) return;
     const U4 r = philox((uint64_t)g + offset, 1u, seed);
@@ -279,6 +313,16 @@ __global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t see
     sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
     const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
     for (int j = 0; j < 4 && i0 + j < n; ++j) out[i0 + j] = v[j];
+}
+__global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
+    fill_normal_body(out, n, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// both per-step draws of the fused step in one launch: blocks [0, gm) draw the keep-mask, the rest the normals
+__global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ mout, long nm, float keep_prob,
+                                 float* __restrict__ eout, long ne, uint64_t seed, uint64_t off_mask,
+                                 uint64_t off_eps, unsigned gm) {
+    if (blockIdx.x < gm) draw_mask_body(in, mout, nm, keep_prob, seed, off_mask, (long)blockIdx.x * blockDim.x + threadIdx.x);
+    else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
 }
 
 }  // namespace vpc
@@ -409,9 +453,28 @@ extern "C" int vpc_loss_finalize(const double* loss_partials, int nblocks, float
                                  float* accum,
                                  void* stream) {
     if (!loss_partials || !out9 || nblocks <= 0 || B_local <= 0 || B_global <= 0) return VPC_ERR_ARG;
-    const double nll_const = 0.91893853320467274178 * (double)B_local * (double)d;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_partials, nblocks, cA0,
-                       cE0, cA1, bq, bp, cr, wml, nll_const, 1.0 / (double)B_global, out9, accum);
+    const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
+                     1.0 / (double)B_global};
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_partials, nblocks, k,
+                       out9, accum);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
+                               int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                               const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
+                               float bp, float cr, float wml, long B_local, long B_global, int d, float* out9,
+                               float* accum, void* stream) {
+    if (!enc_partials || !dec_partials || !grad_idx || !grad_out || !loss_partials || !out9) return VPC_ERR_ARG;
+    if (enc_blocks <= 0 || dec_blocks <= 0 || loss_blocks <= 0 || n_enc <= 0 || n <= n_enc || B_local <= 0 ||
+        B_global <= 0)
+        return VPC_ERR_ARG;
+    const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
+                     1.0 / (double)B_global};
+    const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
+    hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                       enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
+                       loss_blocks, k, out9, accum);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -459,6 +522,16 @@ extern "C" int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, 
     const long groups = (n + 3) / 4;
     hipLaunchKernelGGL(draw_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        mask_in, mask_out, n, keep_prob, (uint64_t)seed, (uint64_t)offset);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out,
+                             long n_eps, unsigned long long seed, unsigned long long offset_mask,
+                             unsigned long long offset_eps, void* stream) {
+    if (!mask_out || !eps_out || n_mask <= 0 || n_eps <= 0) return VPC_ERR_ARG;
+    const unsigned gm = (unsigned)(((n_mask + 3) / 4 + 255) / 256), ge = (unsigned)(((n_eps + 3) / 4 + 255) / 256);
+    hipLaunchKernelGGL(draw_step_kernel, dim3(gm + ge), dim3(256), 0, (hipStream_t)stream, mask_in, mask_out, n_mask,
+                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

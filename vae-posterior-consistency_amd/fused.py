@@ -129,17 +129,27 @@ class FusedTrainer:
         img = m._images()
         enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
         two = not self.vanilla
-        # ---- random draws
+        # ---- random draws (mask_p and eps in ONE launch when both are drawn on the device)
+        need_ml = two and co["wml"] != 0.0
+        draw_eps = eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None)
+        eps_view = self.eps_buf[: (3 if need_ml else 2 if two else 1)]  # only the draws this step consumes
+        n_eps_groups = (eps_view.numel() + 3) // 4
         if two and mask_p is None:
-            ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset)
-            mask_p = self.mask_p_buf
+            off_m = self.rng_offset
             self.rng_offset += (B * d + 3) // 4
+            if draw_eps:
+                ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
+                              self.rng_offset)
+                self.rng_offset += n_eps_groups
+                draw_eps = False
+            else:
+                ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, off_m)
+            mask_p = self.mask_p_buf
         elif two:
             mask_p = as_mask_u8(mask_p)
-        need_ml = two and co["wml"] != 0.0
-        if eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None):
-            ops.fill_normal(self.eps_buf, self.seed, self.rng_offset)
-            self.rng_offset += (self.eps_buf.numel() + 3) // 4
+        if draw_eps:
+            ops.fill_normal(eps_view, self.seed, self.rng_offset)
+            self.rng_offset += n_eps_groups
         if eps_q is not None:  # injected draws (parity tests) arrive dense [B][L]; pad entries are ignored
             self.eps_buf[0, :, :Ld].copy_(eps_q)
         if two and eps_p is not None:
@@ -160,12 +170,11 @@ class FusedTrainer:
                           self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
                           self.dlogvar, self.partE, d, Ld, LP)
-        # ---- flat gradient + loss terms
-        ops.reduce_partials(self.partE, nbE, lay.enc_part, self.gidx[:lay.n_enc], self.grad[:lay.n_enc])
-        ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], self.grad[lay.n_enc:])
+        # ---- flat gradient + loss terms: one launch
         cA1 = co["cA"][1] if two else 0.0
-        ops.loss_finalize(self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B,
-                          Bg, d, self.out9, self.accum if self.world_size == 1 else None)
+        ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part, self.gidx, self.grad, lay.n_enc,
+                        self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg,
+                        d, self.out9, self.accum if self.world_size == 1 else None)
         if self.world_size > 1:
             self._allreduce()
             self.accum += self.out9[0]

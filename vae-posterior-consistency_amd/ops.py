@@ -105,9 +105,22 @@ def loss_finalize(loss_part, nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B
                                   ptr(out9), ptr(accum), stream_ptr()), "vpc_loss_finalize")
 
 
+def reduce_step(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq, bp,
+                cr, wml, B_local, B_global, d, out9, accum=None):
+    check(lib().vpc_reduce_step(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(grad), n_enc,
+                                grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d,
+                                ptr(out9), ptr(accum), stream_ptr()), "vpc_reduce_step")
+
+
 def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
     check(lib().vpc_draw_mask(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), int(seed), int(offset),
                               stream_ptr()), "vpc_draw_mask")
+
+
+def draw_step(mask_in, mask_out, keep_prob, eps_out, seed, offset_mask, offset_eps):
+    check(lib().vpc_draw_step(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), ptr(eps_out),
+                              eps_out.numel(), int(seed), int(offset_mask), int(offset_eps), stream_ptr()),
+          "vpc_draw_step")
 
 
 def fill_normal(out, seed, offset):
