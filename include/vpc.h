@@ -147,6 +147,21 @@ int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float 
 /* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392). */
 int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);
 
+/* ---- active variable selection reward (config 5) -------------------------------------------------------
+ * Replaces the candidate loop of active_learning_func (src/experiment_main/evaluate.py:424-433) and the
+ * functions it calls, R_lindley_chain / chaini_I / chaini_II (evaluate.py:514-634): for every row n and every
+ * feature u < d-1 with mask[n][u] == 0
+ *     R[n][u] = 1/M sum_m [ KL_I(n,u,m) - KL_II(n,u,m) ]          (-1e4 where mask[n][u] != 0)
+ * with the reference's KL expression (first term divided by the std, evaluate.py:582-583) and its carry-over of
+ * the imputed target between MC samples (evaluate.py:531-536).  x [n][d], mask [n][d] bytes, im [M][n][d]
+ * (MC imputations, evaluate.py:396-414), W1 [100][d] / b1 [100] = seq_encoder.0 (flat parameter views),
+ * enc_img = packed encoder image; pre / stat / w1t are scratch buffers of the sizes vpc_reward_scratch returns
+ * (16-byte aligned).  The target is the last column, as in the reference. */
+int vpc_reward_scratch(int n, int d, int M, long* pre_floats, long* stat_floats, long* w1t_floats);
+int vpc_reward_matrix(const float* x, const uint8_t* mask, const float* im, const float* W1, const float* b1,
+                      const float* enc_img, float* pre, float* stat, float* w1t, float* R, int n, int d, int L, int M,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,58 @@ def adam_reference(params, grads_seq, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
             vh = v_[k] / (1 - b2 ** t)
             P[k] = P[k] - lr * mh / (np.sqrt(vh) + eps)
     return P
+
+
+# --------------------------------------------------------------------------
+# active variable selection reward (config 5): src/experiment_main/evaluate.py:514-634
+# --------------------------------------------------------------------------
+def chain_kl(mean, logvar, mean_i, logvar_i):
+    """evaluate.py:582-583 / 631-632: note the first term divides by v = exp(logvar/2) (the std), not the
+    variance - a quirk of the reference that is reproduced as is."""
+    var, v, var_i = torch.exp(logvar), torch.exp(logvar / 2), torch.exp(logvar_i)
+    return 0.5 * torch.sum(torch.square(mean_i - mean) / v + var_i / var - 1.0 - logvar_i + logvar, 1)
+
+
+def chaini_I(port: "TorchPort", x, mask, i):
+    """evaluate.py:546-586 (the z drawn by encoder(sample=True) is discarded, so sample=False is equivalent)."""
+    tm = mask.clone()
+    _, mean, logvar = port.encoder(x, tm, sample=False)
+    tm[:, i] = 1
+    _, mean_i, logvar_i = port.encoder(x, tm, sample=False)
+    return chain_kl(mean, logvar, mean_i, logvar_i)
+
+
+def chaini_II(port: "TorchPort", x, mask, i):
+    """evaluate.py:590-634: as chaini_I with the target (last column) revealed in both encodings."""
+    tm = mask.clone()
+    tm[:, -1] = 1
+    _, mean, logvar = port.encoder(x, tm, sample=False)
+    tm[:, i] = 1
+    _, mean_i, logvar_i = port.encoder(x, tm, sample=False)
+    return chain_kl(mean, logvar, mean_i, logvar_i)
+
+
+def R_lindley_chain(port: "TorchPort", i, x, mask, M, im, loc):
+    """evaluate.py:514-542.  `temp_x[loc, -1]` is not reset between MC samples, so from the second sample on
+    chaini_I sees the previous sample's imputed target when the target column is observed - kept as is."""
+    im_i, im_target = im[:, :, i], im[:, :, -1]
+    temp_x = x.clone()
+    approx = 0
+    for m in range(M):
+        temp_x[loc, i] = im_i[m, loc].float()
+        approx = approx + chaini_I(port, temp_x[loc, :], mask[loc, :], i)
+        temp_x[loc, -1] = im_target[m, loc].float()
+        approx = approx - chaini_II(port, temp_x[loc, :], mask[loc, :], i)
+    return approx / M
+
+
+def reward_matrix(port: "TorchPort", x, mask, M, im):
+    """The candidate loop of active_learning_func (evaluate.py:424-433): R[n, u] for every unobserved feature u
+    of every row, -1e4 elsewhere."""
+    n, d = x.shape
+    R = -1e4 * torch.ones(n, d - 1)
+    for u in range(d - 1):
+        loc = np.where(mask[:, u].numpy() == 0)[0]
+        if len(loc):
+            R[loc, u] = R_lindley_chain(port, u, x, mask, M, im, loc).float()
+    return R

@@ -254,10 +254,43 @@ def gen_train_e2e(d=14, N=96, B=32, epochs=2, seed=99):
     print("train e2e done")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--reward" not in sys.argv:
     for d in (14, 128):
         gen_reg(d)
         gen_vanilla(d)
     gen_traj("reg")
     gen_traj("vanilla")
     gen_train_e2e()
+
+
+def gen_reward(d=14, n=24, M=5, seed=2024):
+    """R_lindley_chain / chaini_I / chaini_II of the reference (evaluate.py:514-634) on a Reg_VAE, float 0/1 masks
+    (as active_learning.py passes them), one case with the target column partly observed (exercises the
+    temp_x[loc,-1] carry-over between MC samples)."""
+    from src.experiment_main.evaluate import R_lindley_chain, chaini_I, chaini_II
+    torch.manual_seed(seed)
+    model = Reg_VAE(d, 500, 10, L, TP, "exp", "kl_reg")
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.rand(n, d, generator=g)
+    out = {"param." + k: v for k, v in sd_np(model).items()}
+    im = torch.rand(M, n, d, generator=g)
+    for tag, target_obs in (("t0", 0.0), ("t1", 0.5)):
+        mask = (torch.rand(n, d, generator=g) < 0.6).float()
+        mask[:, -1] = (torch.rand(n, generator=g) < target_obs).float()
+        R = -1e4 * torch.ones(n, d - 1)
+        with torch.no_grad():
+            for u in range(d - 1):
+                loc = np.where(mask[:, u] == 0)[0]
+                if len(loc):
+                    R[loc, u] = R_lindley_chain(u, x, mask, M, model, im, loc).float()
+            k1 = chaini_I(x, mask, 3, model)
+            k2 = chaini_II(x, mask, 3, model)
+        out.update({f"mask_{tag}": mask.numpy(), f"R_{tag}": R.numpy(), f"kl1_{tag}": k1.numpy(), f"kl2_{tag}": k2.numpy()})
+    out.update(x=x.numpy(), im=im.numpy())
+    np.savez_compressed(os.path.join(OUT, f"reward_d{d}.npz"), **out)
+    print("reward golden done", float(out["R_t0"].max()))
+
+
+if __name__ == "__main__" and "--reward" in sys.argv:
+    gen_reward()
+    gen_reward(d=40, n=20, M=19, seed=77)

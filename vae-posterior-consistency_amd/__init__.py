@@ -11,6 +11,9 @@ from .fused import FusedTrainer
 from .harness import create_missing_uci, model_loader, checkpoint_path, train
 from . import ops
 from . import dist as dp
+from . import active
+from .active import reward_matrix, R_lindley_chain, chaini_I, chaini_II
 
 __all__ = ["Reg_VAE", "vanilla_VAE", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train",
-           "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH"]
+           "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH", "active", "reward_matrix", "R_lindley_chain", "chaini_I",
+           "chaini_II"]

@@ -51,6 +51,8 @@ _PROTOS = {
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
     "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P],
+    "vpc_reward_scratch": [I, I, I, C.POINTER(L_), C.POINTER(L_), C.POINTER(L_)],
+    "vpc_reward_matrix": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
 }
 
 _lib = None

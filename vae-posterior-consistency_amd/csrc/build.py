@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_misc.hip"]
+SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_misc.hip", "vpc_reward.hip"]
 HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h"]
 LIB = os.path.join(HERE, "libvpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -53,7 +53,7 @@ def build(force=False, asm=False):
             o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
             if os.path.exists(o):
                 os.remove(o)
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda s: _compile(s, asm), SRCS))
     if _newer(LIB, objs):
         r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, cwd=HERE,
