@@ -363,3 +363,51 @@ def test_train_harness_fused_and_api(tmp_path, monkeypatch):
                               p_missingness=30)
         for a, b in zip(m.trainable(), m2.trainable()):
             assert torch.equal(a.detach().cpu(), b.detach().cpu())
+
+
+@pytest.mark.parametrize("kind", ["reg", "vanilla"])
+def test_eval_vae_matches_oracle(kind, tmp_path, monkeypatch):
+    """eval_vae restated (evaluate.py:136-297): RMSE on the unobserved entries, ELBO, NLL observed / imputed, M
+    Monte-Carlo passes.  The device eps stream is replayed (torch.manual_seed) to feed the CPU oracle."""
+    monkeypatch.chdir(tmp_path)
+    d, N, Bs, M = 14, 96, 32, 3
+    params = O.init_params(d, L, seed=21)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(N, d, generator=g)
+    mask = torch.rand(N, d, generator=g) < 0.7
+    loader = [(x[i:i + Bs], mask[i:i + Bs]) for i in range(0, N, Bs)]
+    cls = vpc.Reg_VAE if kind == "reg" else vpc.vanilla_VAE
+    m = make_model(cls, d, params)
+    vt = "reg_vae1" if kind == "reg" else "vanilla_vae1"
+    torch.manual_seed(77)
+    out = vpc.eval_vae([(loader, "test")], 30, d, 500, 10, M, L, "synth", TP, "exp", vt, 100, 5, 1, device=torch.device(DEV),
+                       alpha=1.0, stage="evaluate", p_missingness=30, reg_type="kl_reg", beta=1.0, model=m)["test"]
+    # replay
+    torch.manual_seed(77)
+    port = O.TorchPort(params, L)
+    rm, el, nl, ni = [], [], [], []
+    for _ in range(M):
+        r_, e_, n_, i_ = [], [], [], []
+        for xb, mb in loader:
+            eq = torch.randn(xb.shape[0], L, device=DEV).cpu()
+            if kind == "reg":
+                torch.randn(xb.shape[0], L, device=DEV)  # eps_p, drawn by forward() but unused at stage=evaluate
+            zq, mq, lq = port.encoder(xb, mb, eq)
+            xq, xlv = port.decoder(zq)
+            if kind == "reg":
+                r = port.reg_loss(xb, xq, xlv, mq, lq, xq, xlv, mq, lq, mb, mb, 100, llh_eval=True, beta=1.0, alpha=1.0,
+                                  stage="evaluate")
+            else:
+                r = port.vanilla_loss(xb, xq, xlv, mq, lq, 100, mb * 1.0, llh_eval=True, beta=1.0, stage="evaluate")
+            inv = ~mb
+            r_.append(torch.sqrt(torch.sum(torch.square(xq * inv - xb * inv)) / torch.sum(inv)))
+            e_.append(r[1]); n_.append(r[2]); i_.append(r[3])
+        rm.append(torch.stack(r_).mean()); el.append(torch.stack(e_).mean())
+        nl.append(torch.stack(n_).mean()); ni.append(torch.stack(i_).mean())
+    want = dict(rmse=torch.stack(rm).mean(), elbo=torch.stack(el).mean(), negll=torch.stack(nl).mean(),
+                negll_imp=torch.stack(ni).mean())
+    for k in want:
+        assert abs(out[k].item() - want[k].item()) <= 3e-5 * abs(want[k].item()), (k, out[k].item(), want[k].item())
+    import os
+    for pth in vpc.result_paths("exp", "synth", vt, "test", 30, 1.0, 30, "kl_reg").values():
+        assert os.path.exists(pth)

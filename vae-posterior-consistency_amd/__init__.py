@@ -8,12 +8,12 @@ from . import _lib
 from ._lib import VpcError, LIB_PATH
 from .models import Reg_VAE, vanilla_VAE, MAX_EPOCH
 from .fused import FusedTrainer
-from .harness import create_missing_uci, model_loader, checkpoint_path, train
+from .harness import create_missing_uci, model_loader, checkpoint_path, train, eval_vae, result_paths
 from . import ops
 from . import dist as dp
 from . import active
 from .active import reward_matrix, R_lindley_chain, chaini_I, chaini_II
 
-__all__ = ["Reg_VAE", "vanilla_VAE", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train",
+__all__ = ["Reg_VAE", "vanilla_VAE", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
            "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH", "active", "reward_matrix", "R_lindley_chain", "chaini_I",
            "chaini_II"]

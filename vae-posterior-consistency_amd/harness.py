@@ -4,6 +4,7 @@
   model_loader         src/utils/loaders.py:13-246   vae_type substring dispatch + checkpoint naming
   checkpoint_path      src/experiment_main/train.py:120-131
   train                src/experiment_main/train.py:13-133   epoch / batch loop, Adam(lr=1e-3), save at end
+  eval_vae             src/experiment_main/evaluate.py:136-297  M MC passes: imputation RMSE on ~mask, ELBO, NLL
 
 Only the classes named by the hot path are built (Reg_VAE, vanilla_VAE); other vae_type families raise
 NotImplementedError (out of scope).
@@ -124,3 +125,81 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
     print("Training is over!")
     return model
+
+
+def result_paths(experiment_type, data_type, vae_type, loader_stage, missing_rate, alpha=0.5, p_missingness=30,
+                 reg_type="ml_reg"):
+    """File names eval_vae writes (evaluate.py:247-297): rmse, vae_elbo, negative_llh(_q), negative_llh(_q)_imputed."""
+    fam = _family(vae_type)
+    rest = os.path.join("experiments", experiment_type, data_type, "rest", fam)
+    elbo = os.path.join("experiments", experiment_type, data_type, "elbos", fam)
+    pre = f"{loader_stage}_{vae_type}"
+    if "vanilla" in vae_type:
+        suf = f"_{missing_rate}_missing_rate_test.pt"
+        return dict(rmse=os.path.join(rest, pre + "_rmse" + suf), elbo=os.path.join(elbo, pre + "_vae_elbo" + suf),
+                    negll=os.path.join(rest, pre + "_negative_llh" + suf),
+                    negll_imp=os.path.join(rest, pre + "_negative_llh_imputed" + suf))
+    suf = f"_{alpha}_{p_missingness}_{reg_type}_{missing_rate}_missing_rate_full_reg_test.pt"
+    return dict(rmse=os.path.join(rest, pre + "_rmse" + suf), elbo=os.path.join(elbo, pre + "_vae_elbo" + suf),
+                negll=os.path.join(rest, pre + "_negative_llh_q" + suf),
+                negll_imp=os.path.join(rest, pre + "_negative_llh_q_imputed" + suf))
+
+
+def eval_vae(list_loaders, missing_rate, obs_dim, hid_dim, K, M, latent_dim, data_type, training_parameters,
+             experiment_type, vae_type, max_epochs, valid_k, num_estimates, device=torch.device("cuda"), alpha=0.5,
+             stage="evaluate", p_missingness=30, reg_type="ml_reg", beta=1.0, beta_annealing=False,
+             alpha_annealing=True, model=None, save=True):
+    """evaluate.py:136-297 for reg_vae* / vanilla_vae*: reload the checkpoint (or use `model`), and for every
+    (loader, loader_stage): M Monte-Carlo passes of forward + loss(llh_eval=True, stage) per batch; RMSE of the
+    imputations on the UNobserved entries, mean ELBO, NLL on observed and on imputed entries.  Returns
+    {loader_stage: dict(rmse, elbo, negll, negll_imp)} and (save=True) writes the reference's four files."""
+    out = {}
+    with torch.no_grad():
+        if model is None:
+            model = model_loader("test", obs_dim, hid_dim, K, latent_dim, missing_rate, data_type, training_parameters,
+                                 max_epochs, valid_k, num_estimates, experiment_type, reg_type, vae_type, alpha=alpha,
+                                 p_missingness=p_missingness)
+        model.to(device)
+        opt_epoch = max_epochs
+        is_reg = "reg_vae" in vae_type
+        for loader, loader_stage in list_loaders:
+            recon, res, res_negll, res_negll_imp = [], [], [], []
+            for _ in range(M):
+                elbos, negls, negls_imp, temp_recon = [], [], [], []
+                for data_sample, mask in loader:
+                    data_sample, mask = data_sample.to(device), mask.to(device)
+                    if is_reg:  # evaluate.py:172-173, 210-216
+                        mask_p = create_missing_uci(data_sample.shape, p_missingness, device=device) * mask
+                        o = model.forward(data_sample, mask, mask_p, stage=stage)
+                        _, train_loss, negl, negl_imp = model.loss(
+                            data_sample, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mask_p, opt_epoch,
+                            llh_eval=True, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
+                            alpha_annealing=alpha_annealing, stage=stage)
+                        x_mean = o[6]
+                    else:  # evaluate.py:219-227
+                        o = model.forward(data_sample, mask)
+                        _, train_loss, negl, negl_imp = model.loss(data_sample, o[2], o[3], o[0], o[1], opt_epoch, mask,
+                                                                   llh_eval=True, beta_annealing=beta_annealing,
+                                                                   beta=beta, stage=stage)
+                        x_mean = o[2]
+                    mask = mask.reshape(-1, obs_dim)
+                    inv = ~mask if mask.dtype == torch.bool else (mask == 0)
+                    temp_recon.append(torch.sqrt(torch.sum(torch.square(
+                        torch.squeeze(x_mean) * inv - data_sample.view(-1, obs_dim) * inv)) / torch.sum(inv)))
+                    elbos.append(train_loss)
+                    negls.append(torch.as_tensor(negl, device=device, dtype=torch.float32))
+                    negls_imp.append(torch.as_tensor(negl_imp, device=device, dtype=torch.float32))
+                recon.append(torch.stack(temp_recon).mean())
+                res.append(torch.mean(torch.stack(elbos)))
+                res_negll.append(torch.mean(torch.stack(negls)))
+                res_negll_imp.append(torch.mean(torch.stack(negls_imp)))
+            r = dict(rmse=torch.stack(recon).mean(), elbo=torch.stack(res).mean(), negll=torch.stack(res_negll).mean(),
+                     negll_imp=torch.stack(res_negll_imp).mean())
+            out[loader_stage] = {k: v.cpu() for k, v in r.items()}
+            if save:
+                paths = result_paths(experiment_type, data_type, vae_type, loader_stage, missing_rate, alpha,
+                                     p_missingness, reg_type)
+                for k, pth in paths.items():
+                    os.makedirs(os.path.dirname(pth), exist_ok=True)
+                    torch.save(out[loader_stage][k], pth)
+    return out
