@@ -34,14 +34,16 @@ extern "C" {
 
 /* ---- host-side layout queries (no GPU needed) --------------------------------------------------- */
 
-/* Sizes (in elements) for model (d, L).  Any out pointer may be NULL. */
-int vpc_layout_sizes(int d, int L, int* enc_img_floats, int* dec_img_floats, int* n_enc_params, int* n_params,
-                     int* enc_part_floats, int* dec_part_floats, int* loss_terms, int* tile_rows);
+/* Sizes (in elements) for model (d, L).  Any out pointer may be NULL.  mask_augm != 0 selects the
+ * mask-augmented encoder of Reg_VAE_mask / vanilla_VAE_mask (src/models/VAE.py:510-667, 995-1116): the encoder
+ * input is [x*mask | mask] of width 2d (needs 2d <= 128), seq_encoder.0.weight is [100][2d]. */
+int vpc_layout_sizes(int d, int L, int mask_augm, int* enc_img_floats, int* dec_img_floats, int* n_enc_params,
+                     int* n_params, int* enc_part_floats, int* dec_part_floats, int* loss_terms, int* tile_rows);
 
 /* HOST arrays: pack_idx[n_params] (offset of flat parameter i in the combined image [enc | dec]),
  * grad_idx[n_params] (offset of its gradient inside an encoder (i < n_enc) / decoder partial block),
  * img_template[enc_img_floats + dec_img_floats] (zeros plus the constant ones of the bias chain). */
-int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, float* img_template);
+int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int* grad_idx, float* img_template);
 
 /* Compute units of the current device = maximum number of workgroups (partial blocks) any kernel uses. */
 int vpc_num_cus(void);
@@ -69,15 +71,16 @@ int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * 16-byte aligned workspaces of the fused path, pad entries written as 0; z must then be NULL). */
 int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                    float* const* logvar, float* const* z, int lat_pitch, long B, int d, int L, void* stream);
+                    float* const* logvar, float* const* z, int lat_pitch, int mask_augm, long B, int d, int L,
+                    void* stream);
 
 /* Autograd of the above (src/experiment_main/train.py:115): given d loss / d mean and d loss / d logvar
  * (with the reparameterisation path already folded in) accumulate the encoder weight gradients of all
  * passes into partial blocks [*nblocks_out][enc_part_floats].  x needs no gradient (layer-0 dgrad skipped). */
 int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* h1, const float* const* h2, const float* const* dmean,
-                    const float* const* dlogvar, int lat_pitch, float* partials, int* nblocks_out, long B, int d,
-                    int L, void* stream);
+                    const float* const* dlogvar, int lat_pitch, int mask_augm, float* partials, int* nblocks_out,
+                    long B, int d, int L, void* stream);
 
 /* ---- decoder: Reg_VAE.decoder, src/models/VAE.py:397-401 ----------------------------------------- */
 

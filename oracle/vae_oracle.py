@@ -49,11 +49,12 @@ PARAM_KEYS = (
 )
 
 
-def param_shapes(obs_dim: int, latent_dim: int) -> Dict[str, Tuple[int, ...]]:
-    """Shapes of the 12 trainable tensors (src/models/VAE.py:366-376)."""
+def param_shapes(obs_dim: int, latent_dim: int, mask_augm: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """Shapes of the 12 trainable tensors (src/models/VAE.py:366-376; first layer 2d wide for the *_mask
+    classes, VAE.py:527-533)."""
     d, L = obs_dim, latent_dim
     return {
-        "seq_encoder.0.weight": (HID1, d), "seq_encoder.0.bias": (HID1,),
+        "seq_encoder.0.weight": (HID1, 2 * d if mask_augm else d), "seq_encoder.0.bias": (HID1,),
         "seq_encoder.2.weight": (HID2, HID1), "seq_encoder.2.bias": (HID2,),
         "seq_encoder.4.weight": (2 * L, HID2), "seq_encoder.4.bias": (2 * L,),
         "seq_decoder.0.weight": (HID2, L), "seq_decoder.0.bias": (HID2,),
@@ -62,13 +63,13 @@ def param_shapes(obs_dim: int, latent_dim: int) -> Dict[str, Tuple[int, ...]]:
     }
 
 
-def init_params(obs_dim: int, latent_dim: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+def init_params(obs_dim: int, latent_dim: int, seed: int = 0, mask_augm: bool = False) -> Dict[str, torch.Tensor]:
     """nn.Linear default init (Kaiming-uniform a=sqrt(5) == U(-1/sqrt(in), 1/sqrt(in)))."""
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for k, shp in param_shapes(obs_dim, latent_dim).items():
+    for k, shp in param_shapes(obs_dim, latent_dim, mask_augm).items():
         layer = k.rsplit(".", 1)[0]
-        fan_in = param_shapes(obs_dim, latent_dim)[layer + ".weight"][1]
+        fan_in = param_shapes(obs_dim, latent_dim, mask_augm)[layer + ".weight"][1]
         bound = 1.0 / math.sqrt(fan_in)
         out[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
     return out
@@ -80,10 +81,12 @@ def init_params(obs_dim: int, latent_dim: int, seed: int = 0) -> Dict[str, torch
 class TorchPort:
     """Functional restatement of Reg_VAE / vanilla_VAE on stock PyTorch CPU."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], latent_dim: int, reg_type: str = "kl_reg"):
+    def __init__(self, params: Dict[str, torch.Tensor], latent_dim: int, reg_type: str = "kl_reg",
+                 mask_augm: bool = False):
         self.p = params
         self.latent_dim = latent_dim
         self.reg_type = reg_type
+        self.mask_augm = mask_augm  # Reg_VAE_mask / vanilla_VAE_mask (VAE.py:510-667, 995-1116)
         # VAE.py:379 - shape (1,) CPU tensor
         self.x_logvar = torch.log(torch.square(torch.tensor([0.1 * math.sqrt(2.0)])))
         # VAE.py:381-383
@@ -92,7 +95,10 @@ class TorchPort:
     # -- VAE.py:387-395 / 1155-1163
     def encoder(self, x, mask, eps: Optional[torch.Tensor] = None, sample: bool = True):
         p = self.p
-        h = x.float() * mask
+        if self.mask_augm:  # VAE.py:545-548
+            h = torch.stack([x.float() * mask, mask * 1.0], 1).reshape(-1, 2 * x.shape[1])
+        else:
+            h = x.float() * mask
         h = torch.relu(torch.nn.functional.linear(h, p["seq_encoder.0.weight"], p["seq_encoder.0.bias"]))
         h = torch.relu(torch.nn.functional.linear(h, p["seq_encoder.2.weight"], p["seq_encoder.2.bias"]))
         h = torch.nn.functional.linear(h, p["seq_encoder.4.weight"], p["seq_encoder.4.bias"])
@@ -223,10 +229,10 @@ def make_leaf_params(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]
 
 
 def torch_reg_step(params, latent_dim, x, mask, mask_p, eps_q, eps_p, *, reg_type="kl_reg", alpha=1.0,
-                   beta=1.0, beta_annealing=False, epoch=1, eps_ml=None):
+                   beta=1.0, beta_annealing=False, epoch=1, eps_ml=None, mask_augm=False):
     """forward + loss + backward of one Reg_VAE step (train.py:87-115). Returns (loss, grads, outs)."""
     leaf = make_leaf_params(params)
-    port = TorchPort(leaf, latent_dim, reg_type)
+    port = TorchPort(leaf, latent_dim, reg_type, mask_augm)
     outs = port.reg_forward(x, mask, mask_p, eps_q, eps_p)
     mean_p, logvar_p, x_mean_p, x_logvar_p, mean_q, logvar_q, x_mean_q, x_logvar_q = outs
     _, train_loss = port.reg_loss(x, x_mean_p, x_logvar_p, mean_p, logvar_p, x_mean_q, x_logvar_q, mean_q,
@@ -237,9 +243,10 @@ def torch_reg_step(params, latent_dim, x, mask, mask_p, eps_q, eps_p, *, reg_typ
     return train_loss.detach(), grads, [o.detach() for o in outs]
 
 
-def torch_vanilla_step(params, latent_dim, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1):
+def torch_vanilla_step(params, latent_dim, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1,
+                       mask_augm=False):
     leaf = make_leaf_params(params)
-    port = TorchPort(leaf, latent_dim)
+    port = TorchPort(leaf, latent_dim, mask_augm=mask_augm)
     mean_q, logvar_q, x_mean_q, x_logvar_q = port.vanilla_forward(x, mask, eps_q)
     _, train_loss = port.vanilla_loss(x, x_mean_q, x_logvar_q, mean_q, logvar_q, epoch, mask,
                                       beta_annealing=beta_annealing, beta=beta)

@@ -254,7 +254,7 @@ def gen_train_e2e(d=14, N=96, B=32, epochs=2, seed=99):
     print("train e2e done")
 
 
-if __name__ == "__main__" and "--reward" not in sys.argv:
+if __name__ == "__main__" and "--reward" not in sys.argv and "--mask-augm" not in sys.argv:
     for d in (14, 128):
         gen_reg(d)
         gen_vanilla(d)
@@ -294,3 +294,40 @@ def gen_reward(d=14, n=24, M=5, seed=2024):
 if __name__ == "__main__" and "--reward" in sys.argv:
     gen_reward()
     gen_reward(d=40, n=20, M=19, seed=77)
+
+
+def gen_mask_augm(d=14, B=48, seed=555):
+    """Reg_VAE_mask / vanilla_VAE_mask (VAE.py:510-667, 995-1116): forward, one loss, all grads."""
+    from src.models.VAE import Reg_VAE_mask, vanilla_VAE_mask
+    out = {}
+    for kind, cls in (("reg", Reg_VAE_mask), ("vanilla", vanilla_VAE_mask)):
+        torch.manual_seed(seed)
+        model = cls(d, 500, 10, L, TP, "exp", "kl_reg") if kind == "reg" else cls(d, 500, 10, L, TP, "exp")
+        x, mask, mask_p = make_inputs(B, d, seed + 1)
+        out.update({f"{kind}.param." + k: v for k, v in sd_np(model).items()})
+        if kind == "reg":
+            eps_q, eps_p = peek_normals([(B, L), (B, L)])
+            o = model.forward(x, mask, mask_p, "train")
+            _, tl = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mask_p, 1, beta=0.9, alpha=0.7,
+                               stage="train")
+            out.update({"reg.eps_p": eps_p.numpy(), "reg.mean_p": o[0].detach().numpy(), "reg.x_mean_p": o[2].detach().numpy(),
+                        "reg.mean_q": o[4].detach().numpy(), "reg.logvar_q": o[5].detach().numpy(),
+                        "reg.x_mean_q": o[6].detach().numpy()})
+        else:
+            (eps_q,) = peek_normals([(B, L)])
+            mf = mask * torch.ones(x.shape)
+            o = model.forward(x, mf)
+            _, tl = model.loss(x, o[2], o[3], o[0], o[1], 1, mf, beta=0.9, stage="train")
+            out.update({"vanilla.mean_q": o[0].detach().numpy(), "vanilla.x_mean_q": o[2].detach().numpy()})
+        tl.backward()
+        out[f"{kind}.eps_q"] = eps_q.numpy()
+        out[f"{kind}.loss"] = np.array(tl.item(), np.float64)
+        for k, v in grads_np(model).items():
+            out[f"{kind}." + k] = v
+    out.update(x=x.numpy(), mask=mask.numpy(), mask_p=mask_p.numpy())
+    np.savez_compressed(os.path.join(OUT, f"maskaugm_d{d}.npz"), **out)
+    print("mask_augm golden done", out["reg.loss"], out["vanilla.loss"])
+
+
+if __name__ == "__main__" and "--mask-augm" in sys.argv:
+    gen_mask_augm()

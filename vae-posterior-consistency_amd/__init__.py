@@ -6,7 +6,7 @@ The directory name is not a Python identifier; import it as `import vpc_amd` (sh
 """
 from . import _lib
 from ._lib import VpcError, LIB_PATH
-from .models import Reg_VAE, vanilla_VAE, MAX_EPOCH
+from .models import Reg_VAE, vanilla_VAE, Reg_VAE_mask, vanilla_VAE_mask, MAX_EPOCH
 from .fused import FusedTrainer
 from .harness import create_missing_uci, model_loader, checkpoint_path, train, eval_vae, result_paths
 from . import ops
@@ -14,6 +14,6 @@ from . import dist as dp
 from . import active
 from .active import reward_matrix, R_lindley_chain, chaini_I, chaini_II
 
-__all__ = ["Reg_VAE", "vanilla_VAE", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
+__all__ = ["Reg_VAE", "vanilla_VAE", "Reg_VAE_mask", "vanilla_VAE_mask", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
            "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH", "active", "reward_matrix", "R_lindley_chain", "chaini_I",
            "chaini_II"]

@@ -32,14 +32,14 @@ ULL = C.c_ulonglong
 
 # name -> argtypes, in the order of include/vpc.h
 _PROTOS = {
-    "vpc_layout_sizes": [I, I, IP, IP, IP, IP, IP, IP, IP, IP],
-    "vpc_build_indices": [I, I, P, P, P],
+    "vpc_layout_sizes": [I, I, I, IP, IP, IP, IP, IP, IP, IP, IP],
+    "vpc_build_indices": [I, I, I, P, P, P],
     "vpc_num_cus": [],
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
     "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P],
-    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, L_, I, I, P],
-    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, P, IP, L_, I, I, P],
+    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, L_, I, I, P],
+    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
     "vpc_decoder_bwd": [P, P, P, P, P, IP, L_, I, I, P],
     "vpc_loss_fwd_bwd": [P, I, PP, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, P, F, F, F, F, F, F, PP, PP, PP, P, I,
@@ -117,17 +117,18 @@ def require_cuda(*tensors):
 class Layout:
     """Sizes and index tables of the packed layouts for one (d, L)."""
 
-    def __init__(self, d: int, L: int):
+    def __init__(self, d: int, L: int, mask_augm: bool = False):
         l = lib()
+        self.mask_augm = int(bool(mask_augm))
         vals = [C.c_int() for _ in range(8)]
-        check(l.vpc_layout_sizes(d, L, *[C.byref(v) for v in vals]), "vpc_layout_sizes")
+        check(l.vpc_layout_sizes(d, L, self.mask_augm, *[C.byref(v) for v in vals]), "vpc_layout_sizes")
         (self.enc_img, self.dec_img, self.n_enc, self.n_params, self.enc_part, self.dec_part, self.loss_terms,
          self.tile_rows) = [v.value for v in vals]
         self.d, self.L = d, L
         self.pack_idx = np.empty(self.n_params, np.int32)
         self.grad_idx = np.empty(self.n_params, np.int32)
         self.img_template = np.empty(self.enc_img + self.dec_img, np.float32)
-        check(l.vpc_build_indices(d, L, self.pack_idx.ctypes.data_as(P), self.grad_idx.ctypes.data_as(P),
+        check(l.vpc_build_indices(d, L, self.mask_augm, self.pack_idx.ctypes.data_as(P), self.grad_idx.ctypes.data_as(P),
                                   self.img_template.ctypes.data_as(P)), "vpc_build_indices")
         self._dev = {}
 
@@ -142,8 +143,8 @@ class Layout:
 
 
 @lru_cache(maxsize=None)
-def layout(d: int, L: int) -> Layout:
-    return Layout(d, L)
+def layout(d: int, L: int, mask_augm: bool = False) -> Layout:
+    return Layout(d, L, mask_augm)
 
 
 _NCU = None

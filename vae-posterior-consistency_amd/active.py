@@ -20,6 +20,8 @@ def reward_matrix(vae, x, mask, im):
     """R [n, d-1]: reward of revealing feature u for row n (-1e4 where already observed).
     x [n, d]; mask [n, d] (bool / float 0-1 / uint8); im [M, n, d] MC imputations; target = last column."""
     L.require_cuda(x, im)
+    if vae.mask_augm:
+        raise NotImplementedError("reward_matrix: mask-augmented encoders are not supported")
     n, d = x.shape
     M = im.shape[0]
     lay = vae._lay()

@@ -19,6 +19,27 @@ namespace vpc {
 #define VPC_STAMP(i) do {} while (0)
 #endif
 
+// layer-1 input tile t of one row in C layout.  AUG = mask-augmented encoder input [x*mask | mask] of width 2d
+// (Reg_VAE_mask / vanilla_VAE_mask, src/models/VAE.py:545-548): element f < d is x_f * m_f, d <= f < 2d is m_{f-d}.
+template <bool VEC, bool AUG>
+__device__ __forceinline__ f32x4 ld_input(const float* x, const uint8_t* mask, long row, int d, int t, int q, bool ok) {
+    if (!AUG) {
+        const f32x4 xv = ld_tile<VEC>(x, row, d, 16 * t + 4 * q, d, ok);
+        const f32x4 mk = ld_mask<VEC>(mask, row, d, 16 * t + 4 * q, d, ok);
+        return xv * mk;  // x.float() * mask  (VAE.py:388)
+    }
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 16 * t + 4 * q + j;
+        const bool isx = ok && f < d, ism = ok && f >= d && f < 2 * d;
+        const long ix = isx ? row * d + f : 0, im = (isx || ism) ? row * d + (isx ? f : f - d) : 0;
+        const float m = mask[im] ? 1.f : 0.f;
+        v[j] = isx ? x[ix] * m : (ism ? m : 0.f);
+    }
+    return v;
+}
+
 struct EncFwdArgs {
     const float* x;
     const float* img;
@@ -33,7 +54,7 @@ struct EncFwdArgs {
     int d, L, npass, ntiles, lp;
 };
 
-template <int DT, bool VEC>
+template <int DT, bool VEC, bool AUG>
 __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -62,11 +83,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             launder(cc, qq);
             f32x4 xin[DT];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const f32x4 xv = ld_tile<VEC>(a.x, row, a.d, 16 * t + 4 * q, a.d, ok);
-                const f32x4 mk = ld_mask<VEC>(a.mask[p], row, a.d, 16 * t + 4 * q, a.d, ok);
-                xin[t] = xv * mk;  // x.float() * mask  (VAE.py:388)
-            }
+            for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
             VPC_STAMP(1);
             f32x4 h1[H1T];
 #pragma unroll
@@ -128,7 +145,7 @@ struct EncBwdArgs {
 
 constexpr int ENC_CH = 64;  // batch rows per wgrad staging chunk
 
-template <int DT, bool VEC>
+template <int DT, bool VEC, bool AUG>
 __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CH = ENC_CH;
@@ -240,11 +257,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             }
             f32x4 xin[DT];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const f32x4 xv = ld_tile<VEC>(a.x, row, a.d, 16 * t + 4 * q, a.d, ok);
-                const f32x4 mk = ld_mask<VEC>(a.mask[p], row, a.d, 16 * t + 4 * q, a.d, ok);
-                xin[t] = xv * mk;
-            }
+            for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles)
             launder(cc, qq);
             for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
@@ -313,11 +326,11 @@ using namespace vpc;
 
 extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                               float* const* logvar, float* const* z, int lat_pitch, long B, int d, int L,
-                               void* stream) {
+                               float* const* logvar, float* const* z, int lat_pitch, int mask_augm, long B, int d,
+                               int L, void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !mean || !logvar) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
-    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (d < 1 || (mask_augm ? 2 * d : d) > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     if (lat_pitch != L && z) return VPC_ERR_ARG;  // z is only produced in the dense [B][L] layout
     EncFwdArgs a{};
@@ -331,13 +344,14 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
         vec = vec && ((uintptr_t)mask[p] % 4 == 0);
         if (!aligned16(h1[p]) || !aligned16(h2[p])) return VPC_ERR_ARG;
     }
-    const int DT = dt_for(d);
+    const int DT = dt_for(mask_augm ? 2 * d : d);
     const size_t lds = enc_fwd_lds(DT);
     hipStream_t s = (hipStream_t)stream;
 #define VPC_CASE(T)                                                                               \
     case T:                                                                                       \
-        return vec ? launch(enc_fwd_kernel<T, true>, a, a.ntiles, lds, s)                         \
-                   : launch(enc_fwd_kernel<T, false>, a, a.ntiles, lds, s);
+        return mask_augm ? launch(enc_fwd_kernel<T, false, true>, a, a.ntiles, lds, s)            \
+               : vec     ? launch(enc_fwd_kernel<T, true, false>, a, a.ntiles, lds, s)            \
+                         : launch(enc_fwd_kernel<T, false, false>, a, a.ntiles, lds, s);
     switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
     return VPC_ERR_SHAPE;
@@ -345,11 +359,11 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
 
 extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* h1, const float* const* h2, const float* const* dmean,
-                               const float* const* dlogvar, int lat_pitch, float* partials, int* nblocks_out,
-                               long B, int d, int L, void* stream) {
+                               const float* const* dlogvar, int lat_pitch, int mask_augm, float* partials,
+                               int* nblocks_out, long B, int d, int L, void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !dmean || !dlogvar || !partials) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
-    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (d < 1 || (mask_augm ? 2 * d : d) > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     EncBwdArgs a{};
     a.x = x; a.img = enc_img; a.part = partials; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
@@ -362,13 +376,14 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
         if (!aligned16(h1[p]) || !aligned16(h2[p])) return VPC_ERR_ARG;
     }
     if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
-    const int DT = dt_for(d);
+    const int DT = dt_for(mask_augm ? 2 * d : d);
     const size_t lds = enc_bwd_lds(DT);
     hipStream_t s = (hipStream_t)stream;
 #define VPC_CASE(T)                                                                               \
     case T:                                                                                       \
-        return vec ? launch(enc_bwd_kernel<T, true>, a, a.ntiles, lds, s)                         \
-                   : launch(enc_bwd_kernel<T, false>, a, a.ntiles, lds, s);
+        return mask_augm ? launch(enc_bwd_kernel<T, false, true>, a, a.ntiles, lds, s)            \
+               : vec     ? launch(enc_bwd_kernel<T, true, false>, a, a.ntiles, lds, s)            \
+                         : launch(enc_bwd_kernel<T, false, false>, a, a.ntiles, lds, s);
     switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
     return VPC_ERR_SHAPE;

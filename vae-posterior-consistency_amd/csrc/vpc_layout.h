@@ -81,8 +81,11 @@ VPC_HD inline int part_off(int wave, int reg, int row_in_tile, int col_in_tile, 
 // flat parameter order == state_dict order of the 12 trainable tensors
 struct ParamOffsets {
     int w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, w6, b6, n_enc, total;
-    VPC_HD ParamOffsets(int d, int L) {
-        w1 = 0; b1 = w1 + H1 * d; w2 = b1 + H1; b2 = w2 + H2 * H1; w3 = b2 + H2; b3 = w3 + 2 * L * H2;
+    // d_in = width of the encoder input: d, or 2d for the mask-augmented variants ([x*mask | mask],
+    // Reg_VAE_mask / vanilla_VAE_mask, src/models/VAE.py:545-548, 1031-1033)
+    VPC_HD ParamOffsets(int d, int L, int d_in = 0) {
+        if (d_in == 0) d_in = d;
+        w1 = 0; b1 = w1 + H1 * d_in; w2 = b1 + H1; b2 = w2 + H2 * H1; w3 = b2 + H2; b3 = w3 + 2 * L * H2;
         n_enc = b3 + 2 * L;
         w4 = n_enc; b4 = w4 + H2 * L; w5 = b4 + H2; b5 = w5 + H1 * H2; w6 = b5 + H1; b6 = w6 + d * H1;
         total = b6 + d;

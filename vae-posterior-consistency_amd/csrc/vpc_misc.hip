@@ -331,13 +331,14 @@ using namespace vpc;
 
 // ================================================================================================
 // host-side layout queries / index builders (no GPU needed)
-extern "C" int vpc_layout_sizes(int d, int L, int* enc_img_floats, int* dec_img_floats, int* n_enc_params,
-                                int* n_params, int* enc_part_floats, int* dec_part_floats, int* loss_terms,
-                                int* tile_rows) {
-    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+extern "C" int vpc_layout_sizes(int d, int L, int mask_augm, int* enc_img_floats, int* dec_img_floats,
+                                int* n_enc_params, int* n_params, int* enc_part_floats, int* dec_part_floats,
+                                int* loss_terms, int* tile_rows) {
+    const int din = mask_augm ? 2 * d : d;
+    if (d < 1 || din > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     const int DT = dt_for(d);
-    const ParamOffsets po(d, L);
-    if (enc_img_floats) *enc_img_floats = EncImg(DT).total;
+    const ParamOffsets po(d, L, din);
+    if (enc_img_floats) *enc_img_floats = EncImg(dt_for(din)).total;
     if (dec_img_floats) *dec_img_floats = DecImg(DT).total;
     if (n_enc_params) *n_enc_params = po.n_enc;
     if (n_params) *n_params = po.total;
@@ -351,20 +352,21 @@ extern "C" int vpc_layout_sizes(int d, int L, int* enc_img_floats, int* dec_img_
 // pack_idx[i]: offset of flat parameter i inside the combined image buffer [enc image | dec image].
 // grad_idx[i]: offset of d loss / d param_i inside the encoder (i < n_enc) or decoder partial block.
 // img_template: combined image with zeros and the constant ones of the bias chain.
-extern "C" int vpc_build_indices(int d, int L, int* pack_idx, int* grad_idx, float* img_template) {
-    if (d < 1 || d > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+extern "C" int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int* grad_idx, float* img_template) {
+    const int din = mask_augm ? 2 * d : d;
+    if (d < 1 || din > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (!pack_idx || !grad_idx || !img_template) return VPC_ERR_ARG;
     const int DT = dt_for(d);
-    const EncImg ei(DT);
+    const EncImg ei(dt_for(din));
     const DecImg di(DT);
-    const ParamOffsets po(d, L);
+    const ParamOffsets po(d, L, din);
     const int S1 = ei.S1, DB = ei.total;  // decoder image base inside the combined buffer
     std::memset(img_template, 0, sizeof(float) * (size_t)(ei.total + di.total));
     // ---- encoder layer 1: explicit bias; b1[100] = 1 seeds the constant chain
     for (int o = 0; o < H1; ++o) {
-        for (int i = 0; i < d; ++i) {
-            pack_idx[po.w1 + o * d + i] = ei.oW1 + o * S1 + swz(i, o);
-            grad_idx[po.w1 + o * d + i] = part_off(i >> 4, 4 * (o >> 4), o & 15, i & 15);
+        for (int i = 0; i < din; ++i) {
+            pack_idx[po.w1 + o * din + i] = ei.oW1 + o * S1 + swz(i, o);
+            grad_idx[po.w1 + o * din + i] = part_off(i >> 4, 4 * (o >> 4), o & 15, i & 15);
         }
         pack_idx[po.b1 + o] = ei.ob1 + o;
         grad_idx[po.b1 + o] = WAVES * GREGS * 64 + o;

@@ -163,13 +163,13 @@ class FusedTrainer:
         epss = [eq, ep] if two else [eq]
         # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
         self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
-                    None, d, Ld, LP)
+                    None, d, Ld, LP, lay.mask_augm)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
         nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
                           self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
                           self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
-                          self.dlogvar, self.partE, d, Ld, LP)
+                          self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm)
         # ---- flat gradient + loss terms: one launch
         cA1 = co["cA"][1] if two else 0.0
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part, self.gidx, self.grad, lay.n_enc,

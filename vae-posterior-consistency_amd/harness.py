@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .fused import FusedTrainer
-from .models import Reg_VAE, vanilla_VAE
+from .models import Reg_VAE, Reg_VAE_mask, vanilla_VAE, vanilla_VAE_mask
 
 _seed_counter = [0]
 
@@ -52,15 +52,15 @@ def model_loader(stage, obs_dim, hid_dim, K, latent_dim, missing_rate, data_type
                  num_samples, num_estimates, experiment_type, reg_type, vae_type="vae", alpha=1.0, p_missingness=30,
                  beta=0.5, beta_annealing=True, alpha_annealing=True, not_miwae_type="changed"):
     """Same positional signature and substring dispatch as loaders.py:13-246 for the in-scope families."""
-    if "flow" in vae_type or "notMIWAE" in vae_type or "EDDI" in vae_type or "MIWAE" in vae_type \
-            or "mask_augm" in vae_type:
+    if "flow" in vae_type or "notMIWAE" in vae_type or "EDDI" in vae_type or "MIWAE" in vae_type:
         raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* are on the accelerated path")
+    augm = "mask_augm" in vae_type  # loaders.py:47, 143
     if "reg_vae" in vae_type:
-        model = Reg_VAE(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, reg_type, num_samples,
-                        num_estimates)
+        model = (Reg_VAE_mask if augm else Reg_VAE)(obs_dim, hid_dim, K, latent_dim, training_parameters,
+                                                    experiment_type, reg_type, num_samples, num_estimates)
     elif "vanilla_vae" in vae_type:
-        model = vanilla_VAE(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples,
-                            num_estimates)
+        model = (vanilla_VAE_mask if augm else vanilla_VAE)(obs_dim, hid_dim, K, latent_dim, training_parameters,
+                                                            experiment_type, num_samples, num_estimates)
     else:
         raise NotImplementedError(f"vae_type {vae_type!r}")
     if stage == "train":

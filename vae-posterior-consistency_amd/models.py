@@ -34,11 +34,15 @@ _DEC = ("seq_decoder.0", "seq_decoder.2", "seq_decoder.4")
 
 
 class _VAEBase(nn.Module):
+    mask_augm = False  # True: encoder input is [x*mask | mask] (the reference's *_mask classes)
+
     def __init__(self, obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples=1,
                  num_estimates=1):
         super().__init__()
-        if obs_dim > 128 or latent_dim > 15:
-            raise L.VpcError("the gfx950 kernels support obs_dim <= 128 and latent_dim <= 15")
+        enc_in = 2 * obs_dim if self.mask_augm else obs_dim
+        if enc_in > 128 or obs_dim > 128 or latent_dim > 15:
+            raise L.VpcError("the gfx950 kernels support encoder inputs <= 128 wide (obs_dim <= 128, or <= 64 for "
+                             "the mask-augmented classes) and latent_dim <= 15")
         self.obs_dim = obs_dim
         self.hid_dim = hid_dim  # ignored by the reference too (VAE.py:366-376 hard-codes 100 / 50)
         self.latent_dim = latent_dim
@@ -48,7 +52,7 @@ class _VAEBase(nn.Module):
         self.training_parameters = training_parameters
         self.experiment_type = experiment_type
         # containers for the parameters (never called as modules); same indices / init as the reference
-        self.seq_encoder = nn.Sequential(nn.Linear(obs_dim, 100), nn.ReLU(), nn.Linear(100, 50), nn.ReLU(),
+        self.seq_encoder = nn.Sequential(nn.Linear(enc_in, 100), nn.ReLU(), nn.Linear(100, 50), nn.ReLU(),
                                          nn.Linear(50, 2 * latent_dim))
         self.seq_decoder = nn.Sequential(nn.Linear(latent_dim, 50), nn.ReLU(), nn.Linear(50, 100), nn.ReLU(),
                                          nn.Linear(100, obs_dim), nn.Sigmoid())
@@ -75,7 +79,7 @@ class _VAEBase(nn.Module):
 
     def _lay(self):
         if self._layout is None:
-            self._layout = L.layout(self.obs_dim, self.latent_dim)
+            self._layout = L.layout(self.obs_dim, self.latent_dim, self.mask_augm)
         return self._layout
 
     def flatten_parameters(self):
@@ -253,3 +257,14 @@ class vanilla_VAE(_VAEBase):
         loss, sums = LossFn.apply(cfg, ops._f32c(x), x_recon_q.contiguous(), None, mean_q.contiguous(),
                                   logvar_q.contiguous(), None, None, None)
         return self._finish(loss, sums, B, d, llh_eval, MI, stage, mean_q, logvar_q)
+
+
+class Reg_VAE_mask(Reg_VAE):
+    """Reg_VAE with the mask-augmented encoder input [x*mask | mask] (first layer 2d -> 100).
+    Reference: src/models/VAE.py:510-667 (identical to Reg_VAE apart from encoder :545-555)."""
+    mask_augm = True
+
+
+class vanilla_VAE_mask(vanilla_VAE):
+    """vanilla_VAE with the mask-augmented encoder input.  Reference: src/models/VAE.py:995-1116."""
+    mask_augm = True

@@ -47,20 +47,21 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
                               int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
 
 
-def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None):
+def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None, mask_augm=False):
     n = len(masks)
     B = x.shape[0]
     check(lib().vpc_encoder_fwd(ptr(x), ptr(enc_img), n, ptr_array(masks),
                                 ptr_array(eps) if eps is not None else None, ptr_array(h1), ptr_array(h2),
                                 ptr_array(mean), ptr_array(logvar), ptr_array(z) if z is not None else None,
-                                lat_pitch or Ld, B, d, Ld, stream_ptr()), "vpc_encoder_fwd")
+                                lat_pitch or Ld, int(mask_augm), B, d, Ld, stream_ptr()), "vpc_encoder_fwd")
 
 
-def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld, lat_pitch=None):
+def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld, lat_pitch=None, mask_augm=False):
     n = len(masks)
     nb = C.c_int(0)
     check(lib().vpc_encoder_bwd(ptr(x), ptr(enc_img), n, ptr_array(masks), ptr_array(h1), ptr_array(h2),
-                                ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, ptr(partials), C.byref(nb),
+                                ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, int(mask_augm), ptr(partials),
+                                C.byref(nb),
                                 x.shape[0], d, Ld, stream_ptr()), "vpc_encoder_bwd")
     return nb.value
 
@@ -143,7 +144,8 @@ class EncoderFn(torch.autograd.Function):
         mean = torch.empty(B, Ld, device=dev)
         logvar = torch.empty(B, Ld, device=dev)
         z = torch.empty(B, Ld, device=dev)
-        encoder_fwd(x, model._enc_img(), [mask_u8], [eps], [h1], [h2], [mean], [logvar], [z], d, Ld)
+        encoder_fwd(x, model._enc_img(), [mask_u8], [eps], [h1], [h2], [mean], [logvar], [z], d, Ld,
+                    mask_augm=lay.mask_augm)
         ctx.model = model
         ctx.save_for_backward(x, mask_u8, eps if eps is not None else torch.empty(0, device=dev), h1, h2, logvar)
         ctx.has_eps = eps is not None
@@ -170,7 +172,8 @@ class EncoderFn(torch.autograd.Function):
             dl = torch.zeros_like(logvar)
         dm, dl = dm.contiguous(), dl.contiguous()
         part = model._partials(dev, "enc")
-        nb = encoder_bwd(x, model._enc_img(), [mask_u8], [h1], [h2], [dm], [dl], part, lay.d, lay.L)
+        nb = encoder_bwd(x, model._enc_img(), [mask_u8], [h1], [h2], [dm], [dl], part, lay.d, lay.L,
+                         mask_augm=lay.mask_augm)
         flat = torch.empty(lay.n_enc, device=dev)
         _, gidx = lay.device_tables(dev)
         reduce_partials(part, nb, lay.enc_part, gidx[:lay.n_enc], flat)
