@@ -137,7 +137,10 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1:
+        torch.distributed.barrier()
     if rank != 0:
+        vpc.dp.shutdown()
         return
     if not (total == total):
         raise SystemExit("loss is NaN")
@@ -169,6 +172,7 @@ def main():
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu"] = value / cb["value"]
     print(json.dumps(out))
+    vpc.dp.shutdown()
 
 
 if __name__ == "__main__":

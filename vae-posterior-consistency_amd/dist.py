@@ -19,9 +19,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()  # rehearsals with more ranks than GPUs share devices (gloo only)
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # VPC_DIST_BACKEND=gloo: rehearse the multi-rank path on a single GPU
+            backend = os.environ.get("VPC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -41,6 +43,11 @@ def broadcast_parameters(flat: torch.Tensor, src=0, group=None):
     """Make every replica start from rank `src`'s weights."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def allreduce_bucket(bucket: torch.Tensor, group=None):
