@@ -58,10 +58,12 @@ int vpc_reduce_partials(const float* partials, int nblocks, long block_stride, c
                         float* grad_out, int n, float scale, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps), no weight decay / amsgrad - src/experiment_main/train.py:21,116.
- * `step` is the 1-based step count.  If pack_idx/img are non-NULL the updated value is also written into
- * the packed image (saves the separate vpc_pack_weights launch). */
+ * `step` is the 1-based step count; if step_dev != NULL the count is read from device memory instead (word 0
+ * of the `state` vpc_reduce_step maintains) so that a captured HIP graph can be replayed.  If pack_idx/img are
+ * non-NULL the updated value is also written into the packed image (saves the vpc_pack_weights launch). */
 int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
-                  float beta1, float beta2, float eps, long step, const int* pack_idx, float* img, void* stream);
+                  float beta1, float beta2, float eps, long step, const long long* step_dev, const int* pack_idx,
+                  float* img, void* stream);
 
 /* ---- encoder: Reg_VAE.encoder / vanilla_VAE.encoder, src/models/VAE.py:387-395, 1155-1163 -------- */
 
@@ -130,11 +132,14 @@ int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float
 
 /* vpc_reduce_partials (encoder) + vpc_reduce_partials (decoder) + vpc_loss_finalize in ONE launch: the whole
  * post-backward reduction of the fused step.  grad_out[0, n_enc) from the encoder blocks, [n_enc, n) from the
- * decoder blocks (grad_idx as returned by vpc_build_indices), out9 / accum as vpc_loss_finalize. */
+ * decoder blocks (grad_idx as returned by vpc_build_indices), out9 / accum as vpc_loss_finalize.  If state != NULL
+ * (two int64 words on the device) the kernel also does state[0] += 1 (optimiser step count) and
+ * state[1] += rng_inc (Philox counter offset): the per-step counters of a replayed HIP graph. */
 int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
                     int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
                     const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq, float bp,
-                    float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum, void* stream);
+                    float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
+                    long long* state, long long rng_inc, void* stream);
 
 /* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
 
@@ -143,9 +148,11 @@ int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, 
 int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob, unsigned long long seed,
                   unsigned long long offset, void* stream);
 
-/* vpc_draw_mask + vpc_fill_normal in one launch (the two per-step draws of the fused step). */
+/* vpc_draw_mask + vpc_fill_normal in one launch (the two per-step draws of the fused step).  If state != NULL,
+ * state[1] (device) is added to both offsets. */
 int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out, long n_eps,
-                  unsigned long long seed, unsigned long long offset_mask, unsigned long long offset_eps, void* stream);
+                  unsigned long long seed, unsigned long long offset_mask, unsigned long long offset_eps,
+                  const long long* state, void* stream);
 
 /* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392). */
 int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);

@@ -411,3 +411,24 @@ def test_eval_vae_matches_oracle(kind, tmp_path, monkeypatch):
     import os
     for pth in vpc.result_paths("exp", "synth", vt, "test", 30, 1.0, 30, "kl_reg").values():
         assert os.path.exists(pth)
+
+
+def test_graph_replay_matches_eager_steps():
+    """FusedTrainer.step_graph (captured HIP graph, device-side step / RNG counters) == the same steps run eagerly:
+    identical Philox streams, identical Adam bias corrections."""
+    d, B = 14, 64
+    params = O.init_params(d, L, seed=9)
+    x, mask, _, _, _ = synth(B, d, seed=4)
+    xd, md = x.to(DEV), mask.to(DEV)
+    m1, m2 = make_model(vpc.Reg_VAE, d, params), make_model(vpc.Reg_VAE, d, params)
+    t1, t2 = vpc.FusedTrainer(m1, seed=3), vpc.FusedTrainer(m2, seed=3)
+    for i in range(6):
+        t1.step(xd, md, alpha=0.9, beta=0.8)
+        t2.step_graph(xd, md, alpha=0.9, beta=0.8)
+        assert abs(t1.loss_value() - t2.loss_value()) <= 1e-6 * abs(t1.loss_value()), i
+    assert torch.equal(m1._flat, m2._flat)
+    assert abs(t1.epoch_total() - t2.epoch_total()) < 1e-3
+    # new inputs are copied into the captured buffers
+    x2 = torch.rand(B, d, device=DEV)
+    t1.step(x2, md, alpha=0.9, beta=0.8); t2.step_graph(x2, md, alpha=0.9, beta=0.8)
+    assert torch.equal(m1._flat, m2._flat)

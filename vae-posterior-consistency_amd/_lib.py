@@ -37,7 +37,7 @@ _PROTOS = {
     "vpc_num_cus": [],
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
-    "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P],
+    "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P, P],
     "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, L_, I, I, P],
     "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
@@ -47,9 +47,9 @@ _PROTOS = {
     "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, P,
                           P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
-    "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
+    "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, C.c_longlong, P],
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
-    "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P],
+    "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P],
     "vpc_reward_scratch": [I, I, I, C.POINTER(L_), C.POINTER(L_), C.POINTER(L_)],
     "vpc_reward_matrix": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],

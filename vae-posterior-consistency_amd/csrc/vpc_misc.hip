@@ -82,9 +82,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 // torch.optim.Adam (no weight decay / amsgrad), src/experiment_main/train.py:21,116; optional re-pack
 __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
                             float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, const int* __restrict__ pack_idx, float* __restrict__ img) {
+                            float bc2_sqrt, const int* __restrict__ pack_idx, float* __restrict__ img,
+                            const long long* __restrict__ step_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (step_dev) {  // graph replay: the step count lives on the device (kernel arguments are frozen)
+        const double t = (double)step_dev[0];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     const float g = grad[i];
     const float mi = b1 * m[i] + (1.f - b1) * g;
     const float vi = b2 * v[i] + (1.f - b2) * g * g;
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restric
                                                           const int* __restrict__ idx, float* __restrict__ grad,
                                                           int n_enc, int n, const double* __restrict__ lp, int nbL,
                                                           LossCoef k, float* __restrict__ out9,
-                                                          float* __restrict__ accum) {
+                                                          float* __restrict__ accum, long long* __restrict__ state,
+                                                          long long rng_inc) {
     __shared__ float shf[8][32];
     __shared__ double shd[32][LOSS_TERMS];
     __shared__ double s[LOSS_TERMS];
@@ -146,7 +153,13 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restric
     const int b = blockIdx.x;
     if (b < gE) reduce_body(partE, nbE, strideE, idx, grad, n_enc, 1.f, b, shf);
     else if (b < gE + gD) reduce_body(partD, nbD, strideD, idx + n_enc, grad + n_enc, n - n_enc, 1.f, b - gE, shf);
-    else finalize_body(lp, nbL, k, out9, accum, shd, s);
+    else {
+        finalize_body(lp, nbL, k, out9, accum, shd, s);
+        if (state && threadIdx.x == 0) {  // device-side step / RNG counters for graph replay
+            state[0] += 1;
+            state[1] += rng_inc;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,7 +333,8 @@ __global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t see
 // both per-step draws of the fused step in one launch: blocks [0, gm) draw the keep-mask, the rest the normals
 __global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ mout, long nm, float keep_prob,
                                  float* __restrict__ eout, long ne, uint64_t seed, uint64_t off_mask,
-                                 uint64_t off_eps, unsigned gm) {
+                                 uint64_t off_eps, unsigned gm, const long long* __restrict__ state) {
+    if (state) { off_mask += (uint64_t)state[1]; off_eps += (uint64_t)state[1]; }
     if (blockIdx.x < gm) draw_mask_body(in, mout, nm, keep_prob, seed, off_mask, (long)blockIdx.x * blockDim.x + threadIdx.x);
     else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
 }
@@ -438,15 +452,16 @@ extern "C" int vpc_reduce_partials(const float* partials, int nblocks, long bloc
 }
 
 extern "C" int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
-                             float beta1, float beta2, float eps, long step, const int* pack_idx, float* img,
-                             void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return VPC_ERR_ARG;
+                             float beta1, float beta2, float eps, long step, const long long* step_dev,
+                             const int* pack_idx, float* img, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || (step < 1 && !step_dev)) return VPC_ERR_ARG;
+    if (step < 1) step = 1;
     if ((pack_idx == nullptr) != (img == nullptr)) return VPC_ERR_ARG;
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), pack_idx,
-                       img);
+                       img, step_dev);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -466,7 +481,7 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
                                int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
                                const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
                                float bp, float cr, float wml, long B_local, long B_global, int d, float* out9,
-                               float* accum, void* stream) {
+                               float* accum, long long* state, long long rng_inc, void* stream) {
     if (!enc_partials || !dec_partials || !grad_idx || !grad_out || !loss_partials || !out9) return VPC_ERR_ARG;
     if (enc_blocks <= 0 || dec_blocks <= 0 || loss_blocks <= 0 || n_enc <= 0 || n <= n_enc || B_local <= 0 ||
         B_global <= 0)
@@ -476,7 +491,7 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
     const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
     hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                        enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
-                       loss_blocks, k, out9, accum);
+                       loss_blocks, k, out9, accum, state, rng_inc);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -529,11 +544,11 @@ extern "C" int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, 
 
 extern "C" int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out,
                              long n_eps, unsigned long long seed, unsigned long long offset_mask,
-                             unsigned long long offset_eps, void* stream) {
+                             unsigned long long offset_eps, const long long* state, void* stream) {
     if (!mask_out || !eps_out || n_mask <= 0 || n_eps <= 0) return VPC_ERR_ARG;
     const unsigned gm = (unsigned)(((n_mask + 3) / 4 + 255) / 256), ge = (unsigned)(((n_eps + 3) / 4 + 255) / 256);
     hipLaunchKernelGGL(draw_step_kernel, dim3(gm + ge), dim3(256), 0, (hipStream_t)stream, mask_in, mask_out, n_mask,
-                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm);
+                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm, state);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

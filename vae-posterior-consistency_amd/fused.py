@@ -113,7 +113,7 @@ class FusedTrainer:
 
     # ------------------------------------------------------------------
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=1.0, beta=1.0,
-             beta_annealing=False, p_missingness=30, global_batch=None, update=True):
+             beta_annealing=False, p_missingness=30, global_batch=None, update=True, _state=None):
         """One training step on the local rows `x` [B, d] (fp32, GPU), `mask` [B, d] (bool / uint8 / float).
         mask_p / eps_* are drawn on the device unless injected (parity tests).  Returns nothing: the loss of
         this step is in `self.out9[0]` (device), the running total in `self.accum` (train.py:117)."""
@@ -129,6 +129,7 @@ class FusedTrainer:
         img = m._images()
         enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
         two = not self.vanilla
+        rng0 = self.rng_offset
         # ---- random draws (mask_p and eps in ONE launch when both are drawn on the device)
         need_ml = two and co["wml"] != 0.0
         draw_eps = eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None)
@@ -139,7 +140,7 @@ class FusedTrainer:
             self.rng_offset += (B * d + 3) // 4
             if draw_eps:
                 ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
-                              self.rng_offset)
+                              self.rng_offset, _state)
                 self.rng_offset += n_eps_groups
                 draw_eps = False
             else:
@@ -174,14 +175,55 @@ class FusedTrainer:
         cA1 = co["cA"][1] if two else 0.0
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part, self.gidx, self.grad, lay.n_enc,
                         self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg,
-                        d, self.out9, self.accum if self.world_size == 1 else None)
+                        d, self.out9, self.accum if self.world_size == 1 else None, _state,
+                        self.rng_offset - rng0 if _state is not None else 0)
         if self.world_size > 1:
             self._allreduce()
             self.accum += self.out9[0]
         if update:
             self.step_count += 1
             ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.pidx, img)
+                          self.betas[1], self.eps, self.pidx, img, None if _state is None else _state[0:1])
+
+    # ------------------------------------------------------------------ HIP-graph replay of the step
+    def step_graph(self, x, mask, *, epoch=1, alpha=1.0, beta=1.0, beta_annealing=False, p_missingness=30):
+        """Same step, replayed from a captured HIP graph (torch.cuda.CUDAGraph): one host call per step instead
+        of six kernel launches - what matters at the reference's own batch sizes (64 / 128), where the step is
+        launch-bound.  Step count and Philox offsets live on the device (`state`), since kernel arguments are
+        frozen in a graph.  Draws are always on the device; the first call with a new (shape, coefficients) runs
+        one eager step and captures.  Single process only (data parallel falls back to step())."""
+        if self.world_size > 1:
+            return self.step(x, mask, epoch=epoch, alpha=alpha, beta=beta, beta_annealing=beta_annealing,
+                             p_missingness=p_missingness)
+        L.require_cuda(x)
+        x = ops._f32c(x)
+        mask = as_mask_u8(mask)
+        co = self.coefficients(epoch, alpha, beta, beta_annealing)
+        key = (tuple(x.shape), p_missingness, tuple(co["cA"]), tuple(co["cE"]), co["bq"], co["bp"], co["cr"], co["wml"])
+        kw = dict(epoch=epoch, alpha=alpha, beta=beta, beta_annealing=beta_annealing, p_missingness=p_missingness)
+        if getattr(self, "_graph_key", None) != key:
+            self.step(x, mask, **kw)  # eager warm-up: also sets the LDS attributes, workspaces, packed image
+            self._gx, self._gmask = x.clone(), mask.clone()
+            self.state = torch.tensor([self.step_count, 0], dtype=torch.int64, device=self.dev)
+            timers, self.timers = self.timers, None
+            base_rng, base_step = self.rng_offset, self.step_count
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step(self._gx, self._gmask, _state=self.state, **kw)
+            self._graph_rng_inc = self.rng_offset - base_rng
+            self.rng_offset, self.step_count = base_rng, base_step  # capture executed nothing
+            self._timer_tick -= 1
+            self.timers = timers
+            self._graph, self._graph_key = g, key
+            return
+        if x.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(x)
+        if mask.data_ptr() != self._gmask.data_ptr():
+            self._gmask.copy_(mask)
+        self._graph.replay()
+        self.step_count += 1
+        self.rng_offset += self._graph_rng_inc
 
     def _allreduce(self):
         """ONE collective per step over the flat bucket [grads | loss terms] (RCCL over xGMI when the process

@@ -42,9 +42,10 @@ def reduce_partials(partials, nblocks, stride, grad_idx, out, scale=1.0):
                                     float(scale), stream_ptr()), "vpc_reduce_partials")
 
 
-def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, pack_idx=None, img=None):
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, pack_idx=None, img=None,
+              step_dev=None):
     check(lib().vpc_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), lr, beta1, beta2, eps,
-                              int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
+                              int(step), ptr(step_dev), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
 
 
 def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None, mask_augm=False):
@@ -107,10 +108,10 @@ def loss_finalize(loss_part, nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B
 
 
 def reduce_step(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq, bp,
-                cr, wml, B_local, B_global, d, out9, accum=None):
+                cr, wml, B_local, B_global, d, out9, accum=None, state=None, rng_inc=0):
     check(lib().vpc_reduce_step(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(grad), n_enc,
                                 grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d,
-                                ptr(out9), ptr(accum), stream_ptr()), "vpc_reduce_step")
+                                ptr(out9), ptr(accum), ptr(state), int(rng_inc), stream_ptr()), "vpc_reduce_step")
 
 
 def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
@@ -118,9 +119,9 @@ def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
                               stream_ptr()), "vpc_draw_mask")
 
 
-def draw_step(mask_in, mask_out, keep_prob, eps_out, seed, offset_mask, offset_eps):
+def draw_step(mask_in, mask_out, keep_prob, eps_out, seed, offset_mask, offset_eps, state=None):
     check(lib().vpc_draw_step(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), ptr(eps_out),
-                              eps_out.numel(), int(seed), int(offset_mask), int(offset_eps), stream_ptr()),
+                              eps_out.numel(), int(seed), int(offset_mask), int(offset_eps), ptr(state), stream_ptr()),
           "vpc_draw_step")
 
 
