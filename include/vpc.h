@@ -172,6 +172,55 @@ int vpc_reward_matrix(const float* x, const uint8_t* mask, const float* im, cons
                       const float* enc_img, float* pre, float* stat, float* w1t, float* R, int n, int d, int L, int M,
                       void* stream);
 
+/* ---- MNAR path (config 3): REG_notMIWAE_v2 / notMIWAE_myversion --------------------------------------
+ * Reference: src/models/VAE.py:2327-2505 and :2691-2847 (encoder d->128->128 ELU + heads, K-fold replicated
+ * draw, decoder L->128->128 ELU + Sigmoid / Hardtanh(-10,0) heads, self-masking missingness model).  The
+ * layers are generic fp32 MFMA GEMMs (any M, N, K), the loss is one fused forward+backward kernel.
+ * Activation codes: 0 none, 1 ELU, 2 Sigmoid for output features < split and Hardtanh(-10,0) from split on,
+ * 3 ReLU.  All matrices row-major with an explicit row pitch (ld*, in floats). */
+
+/* y[M][N] = act(x[M][K] w[N][K]^T + bias[N])            nn.Linear + activation (VAE.py:2343-2363) */
+int vpc_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long M, int N,
+                   int K, int act, int act_split, void* stream);
+
+/* dx[M][K] = ((dy * act'(y_gate)) w[N][K]) * act_prev'(x_out)     data gradient of the same layer.
+ * y_gate (the layer's outputs, activation code `gate`) may be NULL when dy is already the pre-activation
+ * gradient; x_out (the layer's inputs = previous layer's outputs, activation `act_prev`) may be NULL. */
+int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
+                     const float* w, const float* x_out, long ldx, int act_prev, float* dx, long lddx, long M, int N,
+                     int K, void* stream);
+
+/* dw[N][K] (+)= (dy * act'(y_gate))^T x,  db[N] (+)= column sums; split over M into per-workgroup partials in
+ * `scratch` (vpc_linear_wgrad_scratch floats) that are summed in a fixed order.  db may be NULL. */
+long vpc_linear_wgrad_scratch(long M, int N, int K);
+int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
+                     const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
+                     int K, int accumulate, void* stream);
+
+/* z[b*K+k][:] = mean[b] + eps[b][k] * exp(logvar[b]/2), heads = [mean L | logvar L]; eps NULL -> z = mean
+ * (encoder, VAE.py:2382-2391 / :2753-2765) and its backward (sum over the K replicas, plus g_heads if given). */
+int vpc_nm_sample(const float* heads, long ldh, const float* eps, float* z, long ldz, long B, int K, int L,
+                  void* stream);
+int vpc_nm_sample_bwd(const float* dz, long lddz, const float* eps, const float* heads, long ldh, const float* g_heads,
+                      long ldg, float* out, long ldo, long B, int K, int L, void* stream);
+/* out = x * mask (float mask; encoder input VAE.py:2379 / :2750) */
+int vpc_nm_mul(const float* x, const float* mask, float* out, long n, void* stream);
+
+/* Loss of REG_notMIWAE_v2 (mask_p != NULL; VAE.py:2398-2471) or notMIWAE_myversion (mask_p == NULL, eps_kl =
+ * the fresh draw of VAE.py:2791-2798; :2774-2823) and, when g_xm_q != NULL, every gradient: with respect to the
+ * decoder heads (x_mean | x_logvar, rows b*K+k, pitch ldg_*), the encoder heads ([B][2L]), and W / b.
+ * Masks are float 0/1.  out8 (device doubles) = loss, loss_q, loss_p, KL_reg, NLL_E, mean RE_q, sum lse_q,
+ * sum lse_p; means run over B_global rows (data parallel: sum out8[0] over ranks).  xm_imp != NULL also
+ * writes the self-normalised imputation sum_k softmax(-l_w)_k x_mean[b][k] (llh_eval branch :2458-2461). */
+int vpc_nm_loss_blocks(long B);
+long vpc_nm_loss_scratch(long B, int d);
+int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const float* xm_q, const float* xl_q, long ld_q,
+                const float* xm_p, const float* xl_p, long ld_p, const float* heads_q, const float* heads_p, long ldh,
+                const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
+                float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
+                float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8, long B,
+                long B_global, int K, int d, int L, double alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

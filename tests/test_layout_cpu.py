@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "vpc.h")).read()
-    declared = set(re.findall(r"\bint\s+(vpc_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|long)\s+(vpc_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(vpc._lib.exported_symbols())
     h = ctypes.CDLL(vpc.LIB_PATH)
@@ -38,6 +38,12 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert l.vpc_layout_sizes(14, 10, 0, *[None] * 8) == 0
     assert l.vpc_encoder_fwd(None, None, 1, None, None, None, None, None, None, None, 10, 0, 4, 14, 10, None) == 1
     assert l.vpc_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None, None, None, None) == 1
+    # MNAR path: null pointers / bad shapes are rejected before anything touches the device
+    assert l.vpc_linear_fwd(None, 4, None, None, None, 4, 8, 4, 4, 0, 0, None) == 1
+    assert l.vpc_linear_dgrad(None, 4, None, 4, 0, 0, None, None, 4, 0, None, 4, 8, 4, 4, None) == 1
+    assert l.vpc_linear_wgrad(None, 4, None, 4, 0, 0, None, 4, None, None, None, 0, 8, 4, 4, 0, None) == 1
+    assert l.vpc_nm_sample(None, 20, None, None, 10, 4, 2, 10, None) == 1
+    assert l.vpc_linear_wgrad_scratch(0, 4, 4) == 0 and l.vpc_nm_loss_scratch(0, 4) == 0
 
 
 def swz(col, row, S=64):

@@ -1,0 +1,248 @@
+"""GPU parity of the MNAR path through the C ABI:
+  * the fp32 MFMA GEMM entry points (forward / dgrad / wgrad, gates, ragged shapes) against plain torch fp32,
+  * REG_notMIWAE_v2 / notMIWAE_myversion forward, loss, every parameter gradient, the llh_eval branch and a
+    5-step Adam trajectory against vectors captured from the reference itself (tests/golden/nm_*.npz),
+  * the fused loss kernel against the float64 closed form of the oracle.
+Tolerances: loss 1e-4 relative (north_star), gradients 2e-4 of the tensor's max (fp32 MFMA accumulation order)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nm():
+    import vpc_amd
+    from vpc_amd import notmiwae
+    return notmiwae
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _act(v, act, split):
+    if act == 1:
+        return torch.nn.functional.elu(v)
+    if act == 2:
+        return torch.cat([torch.sigmoid(v[:, :split]), torch.nn.functional.hardtanh(v[:, split:], -10.0, 0.0)], 1)
+    if act == 3:
+        return torch.relu(v)
+    return v
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 128, 14, 1), (37, 20, 128, 0), (128, 128, 128, 1), (300, 28, 128, 2),
+                                       (2560, 256, 128, 2), (513, 128, 10, 1), (1000, 130, 70, 3), (129, 5, 3, 0)])
+def test_linear_fwd(nm, M, N, K, act):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    y = torch.full((M, N), float("nan"), device="cuda")
+    split = N // 2
+    nm.linear_fwd(x, w, b, y, M, N, K, act, split)
+    ref = _act(x.double() @ w.double().t() + b.double(), act, split)
+    _close(y, ref, 1e-5, "fwd")
+
+
+@pytest.mark.parametrize("M,N,K,gate,prev", [(37, 20, 128, 0, 1), (300, 28, 128, 2, 1), (2560, 256, 128, 2, 1),
+                                             (513, 128, 10, 0, 0), (1000, 130, 70, 1, 3), (64, 128, 128, 1, 1)])
+def test_linear_dgrad_wgrad(nm, M, N, K, gate, prev):
+    g = torch.Generator(device="cuda").manual_seed(M + 13 * N + K)
+    x_pre = torch.randn(M, K, device="cuda", generator=g)
+    x_out = _act(x_pre, prev, K)                       # layer input = previous layer's output
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    y = _act(torch.randn(M, N, device="cuda", generator=g) * 3, gate, N // 2)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    # reference (float64)
+    yd, xd = y.double(), x_out.double()
+    if gate == 1:
+        gy = torch.where(yd > 0, torch.ones_like(yd), yd + 1)
+    elif gate == 2:
+        s = N // 2
+        gy = torch.cat([yd[:, :s] * (1 - yd[:, :s]), ((yd[:, s:] > -10) & (yd[:, s:] < 0)).double()], 1)
+    elif gate == 3:
+        gy = (yd > 0).double()
+    else:
+        gy = torch.ones_like(yd)
+    dpre = dy.double() * gy
+    if prev == 1:
+        gx = torch.where(xd > 0, torch.ones_like(xd), xd + 1)
+    elif prev == 3:
+        gx = (xd > 0).double()
+    else:
+        gx = torch.ones_like(xd)
+    dx_ref = (dpre @ w.double()) * gx
+    dw_ref = dpre.t() @ xd
+    db_ref = dpre.sum(0)
+    dx = torch.full((M, K), float("nan"), device="cuda")
+    nm.linear_dgrad(dy, w, dx, M, N, K, y_gate=y if gate else None, gate=gate, gate_split=N // 2,
+                    x_out=x_out if prev else None, act_prev=prev)
+    _close(dx, dx_ref, 2e-5, "dgrad")
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    db = torch.full((N,), float("nan"), device="cuda")
+    nm.linear_wgrad(dy, x_out, dw, db, M, N, K, y_gate=y if gate else None, gate=gate, gate_split=N // 2)
+    _close(dw, dw_ref, 2e-5, "wgrad")
+    _close(db, db_ref, 2e-5, "bias grad")
+    # accumulate = 1 adds to the existing contents, bit-reproducibly
+    dw2, db2 = dw.clone(), db.clone()
+    nm.linear_wgrad(dy, x_out, dw2, db2, M, N, K, y_gate=y if gate else None, gate=gate, gate_split=N // 2,
+                    accumulate=True)
+    assert torch.equal(dw2, dw + dw) and torch.equal(db2, db + db)
+
+
+def _load_model(nm, g, cls, prefix="param."):
+    d = g["x"].shape[1]
+    model = cls(d, 500, 10, int(g["L"]), {"batch_size": 128, "patience": 1}, int(g["K"]), 1)
+    sd = {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith(prefix)}
+    model.load_state_dict(sd)
+    return model.cuda()
+
+
+def _grad_check(model, g, tag, tol=2e-4):
+    for k, p in model.named_parameters():
+        ref = g.get(f"grad.{tag}.{k}")
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        _close(p.grad, torch.from_numpy(ref), tol, f"grad {k}")
+
+
+@pytest.mark.parametrize("d", [14, 40])
+def test_reg_against_reference(nm, d):
+    g = load_golden(f"nm_reg_d{d}.npz")
+    model = _load_model(nm, g, nm.REG_notMIWAE_v2)
+    x, m, mp = _dev(g["x"]), _dev(g["mask"]), _dev(g["mask_p"])
+    names = ["mean_p", "logvar_p", "x_mean_p", "x_logvar_p", "mean_q", "logvar_q", "x_mean_q", "x_logvar_q"]
+    for alpha in (1.0, 0.5, 0.0):
+        model.zero_grad()
+        z_q, mean_q, logvar_q = model._encode(x, m, eps=_dev(g["eps_q"]))
+        xm_q, xl_q = model.decoder(z_q)
+        z_p, mean_p, logvar_p = model._encode(x, mp, eps=_dev(g["eps_p"]))
+        xm_p, xl_p = model.decoder(z_p)
+        outs = (mean_p, logvar_p, xm_p, xl_p, mean_q, logvar_q, xm_q, xl_q)
+        for n, o in zip(names, outs):
+            _close(o, torch.from_numpy(g["fwd." + n]), 2e-5, n)
+        pl, tl = model.loss(x, xm_p, xl_p, mean_p, logvar_p, xm_q, xl_q, mean_q, logvar_q, m, mp, 7, alpha=alpha)
+        ref = float(g[f"loss.a{alpha}"])
+        assert abs(tl.item() - ref) <= 1e-4 * abs(ref), (tl.item(), ref)
+        tl.backward()
+        _grad_check(model, g, f"a{alpha}")
+    with torch.no_grad():
+        xm, tl, re = model.loss(x, xm_p, xl_p, mean_p, logvar_p, xm_q, xl_q, mean_q, logvar_q, m, mp, 7, alpha=0.5,
+                                llh_eval=True)
+    _close(xm, torch.from_numpy(g["llh_xm"]), 2e-5, "llh xm")
+    assert abs(re.item() - float(g["llh_re"])) <= 1e-4 * abs(float(g["llh_re"]))
+    assert abs(tl.item() - float(g["llh_loss"])) <= 1e-4 * abs(float(g["llh_loss"]))
+
+
+@pytest.mark.parametrize("d", [14, 40])
+def test_vanilla_against_reference(nm, d):
+    g = load_golden(f"nm_van_d{d}.npz")
+    model = _load_model(nm, g, nm.notMIWAE_myversion)
+    x, m = _dev(g["x"]), _dev(g["mask"])
+    z, mean, logvar = model._encode(x, m, eps=_dev(g["eps_q"]))
+    xm, xl = model.decoder(z)
+    for n, o in zip(["mean", "logvar", "x_mean", "x_logvar"], (mean, logvar, xm, xl)):
+        _close(o, torch.from_numpy(g["fwd." + n]), 2e-5, n)
+    pl, tl = model.loss(x, xm, xl, mean, logvar, 3, m, eps_kl=_dev(g["eps_kl"]))
+    assert abs(tl.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    tl.backward()
+    _grad_check(model, g, "v")
+    with torch.no_grad():
+        xmi, tl2, re = model.loss(x, xm, xl, mean, logvar, 3, m, llh_eval=True, eps_kl=_dev(g["eps_llh"]))
+    _close(xmi, torch.from_numpy(g["llh_xm"]), 2e-5, "llh xm")
+    assert abs(tl2.item() - float(g["llh_loss"])) <= 1e-4 * abs(float(g["llh_loss"]))
+    assert abs(re.item() - float(g["llh_re"])) <= 1e-4 * abs(float(g["llh_re"]))
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_adam_trajectory(nm, kind):
+    """model.forward / loss / backward + optim.Adam exactly as train.py:87-117, eps and mask_p injected."""
+    g = load_golden(f"nm_traj_{kind}_d14.npz")
+    model = _load_model(nm, g, nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion, "param0.")
+    model.flatten_parameters()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, m = _dev(g["x"]), _dev(g["mask"])
+    for s in range(len(g["losses"])):
+        eps = _dev(g["eps"][s])
+        if kind == "reg":
+            mp = _dev(g["mask_p"][s])
+            z_q, mean_q, logvar_q = model._encode(x, m, eps=eps[0])
+            xm_q, xl_q = model.decoder(z_q)
+            z_p, mean_p, logvar_p = model._encode(x, mp, eps=eps[1])
+            xm_p, xl_p = model.decoder(z_p)
+            _, tl = model.loss(x, xm_p, xl_p, mean_p, logvar_p, xm_q, xl_q, mean_q, logvar_q, m, mp, s + 1, alpha=0.5)
+        else:
+            z, mean, logvar = model._encode(x, m, eps=eps[0])
+            xm, xl = model.decoder(z)
+            _, tl = model.loss(x, xm, xl, mean, logvar, s + 1, m, eps_kl=eps[1])
+        opt.zero_grad()
+        tl.backward()
+        opt.step()
+        assert abs(tl.item() - g["losses"][s]) <= 1e-4 * abs(g["losses"][s]), (s, tl.item(), g["losses"][s])
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("param5."):
+            _close(sd[k[7:]], torch.from_numpy(v), 5e-5, k)
+
+
+def test_loss_kernel_vs_closed_form(nm):
+    """Fused loss kernel alone (ragged d = 70 -> two 64-lane slots, K = 7, L = 5) against the float64 closed form."""
+    from oracle import notmiwae_oracle as O
+    rng = np.random.default_rng(5)
+    B, K, d, L = 33, 7, 70, 5
+    x = rng.random((B, d), dtype=np.float32)
+    m = (rng.random((B, d)) < 0.7).astype(np.float32)
+    mp = m * (rng.random((B, d)) < 0.5).astype(np.float32)
+    mk = lambda: (rng.normal(size=(B, L)).astype(np.float32) * 0.5, rng.normal(size=(B, L)).astype(np.float32) * 0.3,
+                  rng.random((B, K, d), dtype=np.float32) * 0.98 + 0.01,
+                  -3 * rng.random((B, K, d), dtype=np.float32))
+    oq, op = mk(), mk()
+    W = rng.normal(size=d).astype(np.float32)
+    b = rng.normal(size=d).astype(np.float32)
+    eps = rng.normal(size=(B, K, L)).astype(np.float32)
+
+    class Stub:  # just enough of the model for NMLossFn's configuration
+        pass
+    for reg in (True, False):
+        ref, gr = O.loss_closed_form(x, m, oq, W, b, K, mask_p=mp if reg else None, outs_p=op if reg else None,
+                                     alpha=0.3, eps_kl=None if reg else eps.astype(np.float64))
+        lv = lambda t: _dev(t).requires_grad_(True)
+        hq = lv(np.concatenate([oq[0], oq[1]], 1))
+        xmq, xlq = lv(oq[2]), lv(oq[3])
+        Wt, bt = lv(W.reshape(1, 1, d)), lv(b.reshape(1, 1, d))
+        cfg = dict(B=B, K=K, d=d, L=L, alpha=0.3, grad=True, impute=False)
+        if reg:
+            hp, xmp, xlp = lv(np.concatenate([op[0], op[1]], 1)), lv(op[2]), lv(op[3])
+            loss, out8, _ = nm.NMLossFn.apply(cfg, _dev(x), _dev(m), _dev(mp), xmq, xlq, hq, xmp, xlp, hp, Wt, bt, None)
+        else:
+            loss, out8, _ = nm.NMLossFn.apply(cfg, _dev(x), _dev(m), None, xmq, xlq, hq, None, None, None, Wt, bt,
+                                              _dev(eps))
+        assert abs(loss.item() - ref) <= 2e-5 * abs(ref), (loss.item(), ref)
+        loss.backward()
+        pairs = [("d_xm_q", xmq), ("d_xl_q", xlq), ("d_W", Wt), ("d_b", bt)]
+        _close(hq.grad, torch.from_numpy(np.concatenate([gr["d_mean_q"], gr["d_logvar_q"]], 1)), 2e-5, "d heads q")
+        if reg:
+            pairs += [("d_xm_p", xmp), ("d_xl_p", xlp)]
+            _close(hp.grad, torch.from_numpy(np.concatenate([gr["d_mean_p"], gr["d_logvar_p"]], 1)), 2e-5, "d heads p")
+        for k, t in pairs:
+            _close(t.grad.reshape(gr[k].shape), torch.from_numpy(gr[k]), 2e-5, k)
+
+
+def test_cpu_tensors_raise(nm):
+    import vpc_amd
+    model = nm.notMIWAE_myversion(14, 500, 10, 10, {"batch_size": 8, "patience": 1}, 4, 1)
+    with pytest.raises(vpc_amd.VpcError):
+        model.forward(torch.rand(8, 14), torch.ones(8, 14))

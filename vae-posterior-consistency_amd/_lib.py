@@ -53,7 +53,20 @@ _PROTOS = {
     "vpc_fill_normal": [P, L_, ULL, ULL, P],
     "vpc_reward_scratch": [I, I, I, C.POINTER(L_), C.POINTER(L_), C.POINTER(L_)],
     "vpc_reward_matrix": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    # MNAR path (config 3)
+    "vpc_linear_fwd": [P, L_, P, P, P, L_, L_, I, I, I, I, P],
+    "vpc_linear_dgrad": [P, L_, P, L_, I, I, P, P, L_, I, P, L_, L_, I, I, P],
+    "vpc_linear_wgrad_scratch": [L_, I, I],
+    "vpc_linear_wgrad": [P, L_, P, L_, I, I, P, L_, P, P, P, L_, L_, I, I, I, P],
+    "vpc_nm_sample": [P, L_, P, P, L_, L_, I, I, P],
+    "vpc_nm_sample_bwd": [P, L_, P, P, L_, P, L_, P, L_, L_, I, I, P],
+    "vpc_nm_mul": [P, P, P, L_, P],
+    "vpc_nm_loss_blocks": [L_],
+    "vpc_nm_loss_scratch": [L_, I],
+    "vpc_nm_loss": [P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, I, P, P, L_, P,
+                    L_, L_, I, I, I, C.c_double, P],
 }
+_RESTYPE_LONG = {"vpc_linear_wgrad_scratch", "vpc_nm_loss_scratch"}
 
 _lib = None
 
@@ -70,7 +83,7 @@ def lib():
         for name, argtypes in _PROTOS.items():
             fn = getattr(handle, name)  # AttributeError here = header / library mismatch
             fn.argtypes = argtypes
-            fn.restype = I
+            fn.restype = L_ if name in _RESTYPE_LONG else I
         _lib = handle
     return _lib
 

@@ -1,0 +1,340 @@
+// Dense affine layers of the MNAR path (REG_notMIWAE_v2 / notMIWAE_myversion, reference src/models/VAE.py:2343-2363,
+// 2378-2397): fp32 MFMA-tiled GEMM + bias + activation, with LDS-staged, XOR-swizzled operand tiles.
+//
+//   forward   Y[m][n]  = act( sum_k X[m][k] W[n][k] + b[n] )                       (nn.Linear + ELU / Sigmoid / Hardtanh)
+//   dgrad     dX[m][k] = ( sum_n dY~[m][n] W[n][k] ) * act'(Xout[m][k])            (autograd of the layer, data side)
+//   wgrad     dW[n][k] = sum_m dY~[m][n] X[m][k],  db[n] = sum_m dY~[m][n]         (weight side; split over m, fixed-order
+//                                                                                    reduction => deterministic)
+// dY~ = dY * act'(Y) can be formed on load (head layers, whose dY arrives from the loss kernel un-gated).
+//
+// One kernel template, three modes.  The MFMA is v_mfma_f32_16x16x4_f32 used "transposed" as everywhere in this
+// library: the D tile is [feature 4q+j][row c], so a lane owns 4 consecutive features of one row and the epilogue
+// moves float4s.  A workgroup (4 waves, 2 x 2) computes a 128 x 128 output tile; the contraction runs in chunks of
+// 64 through two 32 KB LDS tiles:
+//     row-read tile   [128][64]  (operand indexed [output][contraction]): one ds_read_b128 feeds 4 MFMAs
+//     transposed tile [64][128]  (operand indexed [contraction][output]): 4 ds_read_b32 feed 4 MFMAs
+// both with the 16-byte slot index XOR-ed with (row & 15), which makes either read conflict-free
+// (tools/lds_conflicts.py).  Global loads of chunk i+1 are in flight while chunk i is multiplied.
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "../../include/vpc.h"
+
+namespace vpc {
+
+enum { LIN_FWD = 0, LIN_DGRAD = 1, LIN_WGRAD = 2 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID_HARDTANH = 2, ACT_RELU = 3 };
+
+struct LinArgs {
+    const float* A; long lda;      // fwd: W [N][K]       dgrad: W [N][K]       wgrad: dY [M][N]
+    const float* B; long ldb;      // fwd: X [M][K]       dgrad: dY [M][N]      wgrad: X  [M][K]
+    const float* Yg; long ldy;     // optional: outputs of the layer, to gate dY on load (dgrad: B, wgrad: A)
+    float* C; long ldc;            // fwd: Y [M][N]       dgrad: dX [M][K]      wgrad: partials [S][N][K]
+    const float* bias;             // fwd
+    const float* aux; long ldaux;  // dgrad: layer input (= previous layer's output) for act'
+    float* bias_part;              // wgrad: [S][N]
+    int M, N, K;
+    int act, split;                // fwd: output activation; dgrad: activation of the PREVIOUS layer (for aux)
+    int gate, gate_split;          // activation of THIS layer when Yg is given
+    int rows_per_split;            // wgrad
+    int vecA, vecB, vecC;          // 16-byte path usable for the operand / output
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act, bool second) {
+    switch (act) {
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case ACT_SIGMOID_HARDTANH: return second ? fminf(fmaxf(v, -10.f), 0.f) : 1.f / (1.f + expf(-v));
+        case ACT_RELU: return fmaxf(v, 0.f);
+        default: return v;
+    }
+}
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad(float y, int act, bool second) {
+    switch (act) {
+        case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case ACT_SIGMOID_HARDTANH: return second ? ((y > -10.f && y < 0.f) ? 1.f : 0.f) : y * (1.f - y);
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+constexpr int LIN_THREADS = 256;
+constexpr int LIN_TILE = 8192;  // floats per LDS tile
+
+// ---- global -> registers: a ROWS x COLS tile (ROWS * COLS = 8192), zero-filled outside [rlim) x [clim)
+template <int COLS>
+__device__ __forceinline__ void gload(f32x4 (&r)[8], const float* __restrict__ base, long ld, int r0, int c0, int rlim,
+                                      int clim, int vec, const float* __restrict__ yg, long ldy, int gate,
+                                      int gate_split) {
+    constexpr int C4 = COLS / 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + LIN_THREADS * i;
+        const int row = r0 + idx / C4, col = c0 + 4 * (idx % C4);
+        f32x4 v = zero4();
+        if (row < rlim && col < clim) {
+            const float* p = base + (long)row * ld + col;
+            if (vec && col + 3 < clim) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < clim) v[e] = p[e];
+            }
+            if (yg) {
+                const float* py = yg + (long)row * ldy + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < clim) v[e] *= act_grad(py[e], gate, col + e >= gate_split);
+            }
+        }
+        r[i] = v;
+    }
+}
+// ---- registers -> swizzled LDS tile
+template <int COLS>
+__device__ __forceinline__ void sstore(float* __restrict__ s, const f32x4 (&r)[8]) {
+    constexpr int C4 = COLS / 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + LIN_THREADS * i;
+        const int row = idx / C4, sl = idx % C4;
+        *reinterpret_cast<f32x4*>(s + row * COLS + ((sl ^ (row & 15)) << 2)) = r[i];
+    }
+}
+// A/B fragments for output block `ob` (16 outputs) and contraction sub-block kk (16 values): f[j] feeds MFMA k-step j
+__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ s, int ob, int kk, int c, int q) {
+    return *reinterpret_cast<const f32x4*>(s + (16 * ob + c) * 64 + (((4 * kk + q) ^ c) << 2));
+}
+__device__ __forceinline__ f32x4 frag_T(const float* __restrict__ s, int ob, int kk, int c, int q) {
+    f32x4 f;
+    const int cs = 4 * ob + (c >> 2), cl = c & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        f[j] = s[(16 * kk + r) * 128 + (((cs ^ r) << 2) | cl)];
+    }
+    return f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    float* sA = lds;
+    float* sB = lds + LIN_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    constexpr bool AT = MODE != LIN_FWD;    // A operand read transposed
+    constexpr bool BT = MODE == LIN_WGRAD;  // B operand read transposed
+
+    // output tile origin (i0 along the A-operand index, j0 along the B-operand index) and contraction range
+    int i0, j0, k_begin, k_end, ilim, jlim;
+    if (MODE == LIN_FWD) {
+        j0 = blockIdx.x * 128; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.K; ilim = a.N; jlim = a.M;
+    } else if (MODE == LIN_DGRAD) {
+        j0 = blockIdx.x * 128; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.N; ilim = a.K; jlim = a.M;
+    } else {
+        i0 = blockIdx.y * 128; j0 = blockIdx.z * 128; ilim = a.N; jlim = a.K;
+        k_begin = blockIdx.x * a.rows_per_split;
+        k_end = min(a.M, k_begin + a.rows_per_split);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+    float bsum = 0.f;  // wgrad: column sum of dY~ (bias gradient), threads 0..127 of the k-tile-0 workgroups
+
+    f32x4 ra[8], rb[8];
+    auto load_chunk = [&](int k0) {
+        if (MODE == LIN_FWD) {
+            gload<64>(ra, a.A, a.lda, i0, k0, a.N, k_end, a.vecA, nullptr, 0, 0, 0);
+            gload<64>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, nullptr, 0, 0, 0);
+        } else if (MODE == LIN_DGRAD) {
+            gload<128>(ra, a.A, a.lda, k0, i0, k_end, a.K, a.vecA, nullptr, 0, 0, 0);
+            gload<64>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, a.Yg, a.ldy, a.gate, a.gate_split);
+        } else {
+            gload<128>(ra, a.A, a.lda, k0, i0, k_end, a.N, a.vecA, a.Yg, a.ldy, a.gate, a.gate_split);
+            gload<128>(rb, a.B, a.ldb, k0, j0, k_end, a.K, a.vecB, nullptr, 0, 0, 0);
+        }
+    };
+
+    if (k_begin < k_end) load_chunk(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        sstore<AT ? 128 : 64>(sA, ra);
+        sstore<BT ? 128 : 64>(sB, rb);
+        __syncthreads();
+        if (k0 + 64 < k_end) load_chunk(k0 + 64);
+        if (MODE == LIN_WGRAD && blockIdx.z == 0 && threadIdx.x < 128) {
+            const int col = threadIdx.x, cs = col >> 2, cl = col & 3;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) bsum += sA[r * 128 + (((cs ^ (r & 15)) << 2) | cl)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = AT ? frag_T(sA, 4 * wr + t, kk, c, q) : frag_row(sA, 4 * wr + t, kk, c, q);
+                fb[t] = BT ? frag_T(sB, 4 * wc + t, kk, c, q) : frag_row(sB, 4 * wc + t, kk, c, q);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) acc[it][jt] = VPC_MFMA(fa[it][j], fb[jt][j], acc[it][jt]);
+        }
+    }
+
+    // ---- epilogue.  acc[it][jt][e] = D[i0 + 64 wr + 16 it + 4 q + e][j0 + 64 wc + 16 jt + c]
+    if (MODE == LIN_WGRAD) {
+        float* P = a.C + (long)blockIdx.x * a.N * a.ldc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int col = j0 + 64 * wc + 16 * jt + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = i0 + 64 * wr + 16 * it + 4 * q + e;
+                    if (row < ilim && col < jlim) P[(long)row * a.ldc + col] = acc[it][jt][e];
+                }
+            }
+        if (blockIdx.z == 0 && threadIdx.x < 128 && i0 + (int)threadIdx.x < a.N)
+            a.bias_part[(long)blockIdx.x * a.N + i0 + threadIdx.x] = bsum;
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = i0 + 64 * wr + 16 * it + 4 * q;  // first of 4 consecutive output features
+        if (f >= ilim) continue;
+        f32x4 bv = zero4();
+        if (MODE == LIN_FWD && a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (f + e < ilim) bv[e] = a.bias[f + e];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int row = j0 + 64 * wc + 16 * jt + c;
+            if (row >= jlim) continue;
+            f32x4 v = acc[it][jt];
+            if (MODE == LIN_FWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e] + bv[e], a.act, f + e >= a.split);
+            } else if (a.aux) {
+                const float* px = a.aux + (long)row * a.ldaux + f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (f + e < ilim) v[e] *= act_grad(px[e], a.act, f + e >= a.split);
+            }
+            float* pc = a.C + (long)row * a.ldc + f;
+            if (a.vecC && f + 3 < ilim) {
+                *reinterpret_cast<f32x4*>(pc) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (f + e < ilim) pc[e] = v[e];
+            }
+        }
+    }
+}
+
+// sum the per-split partial blocks in split order (deterministic); accumulate != 0 adds to dW / db
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias_part, int S, int N,
+                                    int K, float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+    const long n_w = (long)N * K;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_w) {
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += part[(long)sp * n_w + i];
+        dW[i] = accumulate ? dW[i] + s : s;
+    } else if (i < n_w + N) {
+        const int n = (int)(i - n_w);
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += bias_part[(long)sp * N + n];
+        if (db) db[n] = accumulate ? db[n] + s : s;
+    }
+}
+
+static bool vec_ok(const void* p, long ld) { return aligned16(p) && (ld % 4) == 0; }
+
+template <int MODE>
+static int launch(const LinArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t LDS = 2 * LIN_TILE * sizeof(float);
+    if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE>), LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(linear_kernel<MODE>, grid, dim3(LIN_THREADS), LDS, st, a);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+extern "C" {
+
+int vpc_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long M, int N,
+                   int K, int act, int act_split, void* stream) {
+    if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N || M > 0x7fffff00L) return VPC_ERR_ARG;
+    if (act < ACT_NONE || act > ACT_RELU) return VPC_ERR_ARG;
+    LinArgs a{};
+    a.A = w; a.lda = K; a.B = x; a.ldb = ldx; a.C = y; a.ldc = ldy; a.bias = bias;
+    a.M = (int)M; a.N = N; a.K = K; a.act = act; a.split = act == ACT_SIGMOID_HARDTANH ? act_split : N;
+    a.vecA = vec_ok(w, K); a.vecB = vec_ok(x, ldx); a.vecC = vec_ok(y, ldy);
+    return launch<LIN_FWD>(a, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128)), (hipStream_t)stream);
+}
+
+int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
+                     const float* w, const float* x_out, long ldx, int act_prev, float* dx, long lddx, long M, int N,
+                     int K, void* stream) {
+    if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K || M > 0x7fffff00L) return VPC_ERR_ARG;
+    if ((y_gate && ldyg < N) || (x_out && ldx < K)) return VPC_ERR_ARG;
+    LinArgs a{};
+    a.A = w; a.lda = K; a.B = dy; a.ldb = lddy; a.Yg = y_gate; a.ldy = ldyg; a.gate = gate;
+    a.gate_split = gate == ACT_SIGMOID_HARDTANH ? gate_split : N;
+    a.C = dx; a.ldc = lddx; a.aux = x_out; a.ldaux = ldx; a.act = act_prev; a.split = K;
+    a.M = (int)M; a.N = N; a.K = K;
+    a.vecA = vec_ok(w, K); a.vecB = vec_ok(dy, lddy); a.vecC = vec_ok(dx, lddx);
+    return launch<LIN_DGRAD>(a, dim3((unsigned)((M + 127) / 128), (unsigned)((K + 127) / 128)), (hipStream_t)stream);
+}
+
+long vpc_linear_wgrad_scratch(long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const long chunks = (M + 63) / 64;
+    const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+    long S = (2L * num_cus() + tiles - 1) / tiles;  // ~2 workgroups per CU in total
+    if (S > chunks) S = chunks;
+    if (S < 1) S = 1;
+    return S * ((long)N * K + N);
+}
+
+int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
+                     const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
+                     int K, int accumulate, void* stream) {
+    if (!dy || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || M > 0x7fffff00L)
+        return VPC_ERR_ARG;
+    if (y_gate && ldyg < N) return VPC_ERR_ARG;
+    const long need = vpc_linear_wgrad_scratch(M, N, K);
+    if (scratch_floats < need) return VPC_ERR_ARG;
+    const long S = need / ((long)N * K + N);
+    const long chunks = (M + 63) / 64;
+    const long rows_per_split = ((chunks + S - 1) / S) * 64;
+    LinArgs a{};
+    a.A = dy; a.lda = lddy; a.Yg = y_gate; a.ldy = ldyg; a.gate = gate;
+    a.gate_split = gate == ACT_SIGMOID_HARDTANH ? gate_split : N;
+    a.B = x; a.ldb = ldx; a.C = scratch; a.ldc = K; a.bias_part = scratch + S * (long)N * K;
+    a.M = (int)M; a.N = N; a.K = K; a.rows_per_split = (int)rows_per_split;
+    a.vecA = vec_ok(dy, lddy); a.vecB = vec_ok(x, ldx);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch<LIN_WGRAD>(a, dim3((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128)), st);
+    if (rc != VPC_OK) return rc;
+    const long n = (long)N * K + N;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch,
+                       a.bias_part, (int)S, N, K, dw, db, accumulate);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // extern "C"

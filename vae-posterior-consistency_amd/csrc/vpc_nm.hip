@@ -1,0 +1,402 @@
+// Elementwise / reduction kernels of the MNAR path (reference src/models/VAE.py: REG_notMIWAE_v2 :2327-2505,
+// notMIWAE_myversion :2691-2847).  HBM-bound fp32 work: coalesced row reads, wave-level reductions, no atomics
+// (every cross-row sum goes through fixed-order partials => bit-reproducible).
+//
+//   nm_sample      z[b,k,:] = mean[b] + eps[b,k,:] * exp(logvar[b] / 2)              (encoder :2385-2389 / :2758-2763)
+//   nm_sample_bwd  d heads from dz (sum over the K replicas) + the direct mean/logvar gradients
+//   nm_loss        importance-weighted bound with the self-masking missingness model, forward AND backward in one
+//                  launch: one wave per data row walks its K samples twice (pass 1: l_w and the log-sum-exp,
+//                  pass 2: softmax weights x per-element derivatives), nothing but the inputs and the gradients
+//                  touches HBM (loss :2398-2471 / :2774-2823)
+//   nm_finalize    fixed-order reduction of the per-row statistics and the per-wave dW / db partials
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "../../include/vpc.h"
+
+namespace vpc {
+
+constexpr float NM_HALF_LOG_2PI = 0.91893853320467274f;
+
+struct NMLossArgs {
+    const float* x; const float* m; const float* mp;        // [B][d]; mp = nullptr for the un-regularised model
+    const float* xm_q; const float* xl_q; long ld_q;         // decoder heads of the q pass, rows b*K+k
+    const float* xm_p; const float* xl_p; long ld_p;         // p pass (regularised only)
+    const float* hq; const float* hp; long ldh;              // encoder heads [B][mean L | logvar L]
+    const float* W; const float* b;                          // missingness model, [d]
+    const float* eps_kl;                                     // [B][K][L], un-regularised only (MC KL draw)
+    float* g_xm_q; float* g_xl_q; long ldg_q;                // gradients (nullptr: forward only)
+    float* g_xm_p; float* g_xl_p; long ldg_p;
+    float* g_hq; float* g_hp; long ldgh;                     // [B][2L]
+    float* gwb_part;                                         // [n_waves][2][d]
+    float* xm_imp;                                           // [B][d] self-normalised imputation (llh_eval), or nullptr
+    double* rowstat;                                         // [B][NM_STATS]
+    int B, K, d, L;
+    float oq, op, oe, cr;                                    // gradient weights: (1-a)/B, a/B, a/(BK), a/(BL)
+    float kq, kp;                                            // weights of the analytic KL gradients: (1-a)/B, a/B
+};
+constexpr int NM_STATS = 5;  // lse_q, lse_p, sum_k RE_e, sum_l kl_el, sum_k RE_q
+
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+__device__ __forceinline__ float sigmoid_f(float v) {
+    const float e = expf(-fabsf(v));
+    return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+struct Lse {  // online log-sum-exp
+    float mx = -INFINITY, s = 0.f;
+    __device__ __forceinline__ void add(float v) {
+        if (v > mx) { s = s * expf(mx - v) + 1.f; mx = v; } else s += expf(v - mx);
+    }
+    __device__ __forceinline__ float value() const { return mx + logf(s); }
+};
+
+template <int T, bool REG>
+__global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
+    extern __shared__ float lds[];
+    float* spW = lds;            // softplus(W)
+    float* sgW = lds + a.d;      // sigmoid(W) = d softplus
+    float* bb = lds + 2 * a.d;
+    for (int j = threadIdx.x; j < a.d; j += blockDim.x) {
+        const float w = a.W[j];
+        spW[j] = softplus_f(w); sgW[j] = sigmoid_f(w); bb[j] = a.b[j];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int d = a.d, K = a.K, L = a.L;
+    const bool grad = a.g_xm_q != nullptr;
+    float gW[T], gB[T], sp[T], sg[T], bj[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = lane + 64 * t;
+        gW[t] = gB[t] = 0.f;
+        sp[t] = j < d ? spW[j] : 0.f; sg[t] = j < d ? sgW[j] : 0.f; bj[t] = j < d ? bb[j] : 0.f;
+    }
+    const float cd = NM_HALF_LOG_2PI * (float)d;
+
+    for (int b = gwave; b < a.B; b += nwaves) {
+        float x[T], m[T], mp[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < d;
+            x[t] = ok ? a.x[(long)b * d + j] : 0.f;
+            m[t] = ok ? a.m[(long)b * d + j] : 0.f;
+            mp[t] = (REG && ok) ? a.mp[(long)b * d + j] : 0.f;
+        }
+        // ---- latent statistics (lanes over L)
+        float mu_q = 0.f, lv_q = 0.f, mu_p = 0.f, lv_p = 0.f, sd_q = 0.f;
+        const bool lok = lane < L;
+        if (lok) { mu_q = a.hq[(long)b * a.ldh + lane]; lv_q = a.hq[(long)b * a.ldh + L + lane]; }
+        float KLq = 0.f, KLp = 0.f, klel = 0.f;
+        if (REG) {
+            if (lok) { mu_p = a.hp[(long)b * a.ldh + lane]; lv_p = a.hp[(long)b * a.ldh + L + lane]; }
+            const float eq = expf(lv_q), ep = expf(lv_p), ivp = expf(-lv_p), ratio = expf(lv_q - lv_p);
+            const float dm = mu_q - mu_p;
+            KLq = wave_sum(lok ? 0.5f * (eq + mu_q * mu_q - 1.f - lv_q) : 0.f);
+            KLp = wave_sum(lok ? 0.5f * (ep + mu_p * mu_p - 1.f - lv_p) : 0.f);
+            klel = wave_sum(lok ? 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p)) : 0.f);
+            if (grad && lok) {
+                float* gq = a.g_hq + (long)b * a.ldgh;
+                float* gp = a.g_hp + (long)b * a.ldgh;
+                gq[lane] = a.kq * mu_q + a.cr * dm * ivp;
+                gq[L + lane] = a.kq * 0.5f * (eq - 1.f) + a.cr * 0.5f * (ratio - 1.f);
+                gp[lane] = a.kp * mu_p - a.cr * dm * ivp;
+                gp[L + lane] = a.kp * 0.5f * (ep - 1.f) + a.cr * 0.5f * (1.f - ratio - dm * dm * ivp);
+            }
+        } else {
+            sd_q = expf(0.5f * lv_q);
+        }
+
+        // per-(b,k) terms; returns l_w_q and l_w_p, leaves the element-wise pieces in the out arrays
+        auto terms = [&](int k, float& lwq, float& lwp, float& re_q_out, float& re_e_out, float (&riv)[T],
+                         float (&hq2)[T], float (&dn)[T], float (&mix)[T], float (&rivp)[T], float (&hp2)[T],
+                         float& z_out, float& e_out) {
+            const long row = (long)b * K + k;
+            float s_req = 0.f, s_nlp = 0.f, s_ree = 0.f, s_rep = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = lane + 64 * t;
+                const bool ok = j < d;
+                const float xm = ok ? a.xm_q[row * a.ld_q + j] : 0.f;
+                const float xl = ok ? a.xl_q[row * a.ld_q + j] : 0.f;
+                const float iv = expf(-xl), r = x[t] - xm;
+                riv[t] = r * iv;                       // (x - xm) / var
+                hq2[t] = 0.5f - 0.5f * r * riv[t];     // d/dxl of the element NLL
+                const float el = 0.5f * xl + 0.5f * r * riv[t];
+                s_req += m[t] * el;
+                if (REG) s_ree += m[t] * (1.f - mp[t]) * el;
+                mix[t] = xm * (1.f - m[t]) + x[t] * m[t];
+                const float lg = -sp[t] * (mix[t] - bj[t]);
+                s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + log1pf(expf(-fabsf(lg))) : 0.f;
+                dn[t] = sigmoid_f(lg) - m[t];
+                if (REG) {
+                    const float xmp = ok ? a.xm_p[row * a.ld_p + j] : 0.f;
+                    const float xlp = ok ? a.xl_p[row * a.ld_p + j] : 0.f;
+                    const float ivp = expf(-xlp), rp = x[t] - xmp;
+                    rivp[t] = rp * ivp;
+                    hp2[t] = 0.5f - 0.5f * rp * rivp[t];
+                    s_rep += mp[t] * (0.5f * xlp + 0.5f * rp * rivp[t]);
+                }
+            }
+            float KL = KLq;
+            if (!REG) {
+                const float e = lok ? a.eps_kl[row * L + lane] : 0.f;
+                const float z = mu_q + e * sd_q;
+                z_out = z; e_out = e;
+                KL = wave_sum(lok ? -0.5f * e * e - 0.5f * lv_q + 0.5f * z * z : 0.f);
+            }
+            const float RE_q = wave_sum(s_req) + cd;
+            const float nlp = wave_sum(s_nlp);
+            lwq = RE_q + KL + nlp;
+            re_q_out = RE_q;
+            if (REG) {
+                re_e_out = wave_sum(s_ree) + cd;
+                lwp = wave_sum(s_rep) + cd + KLp;
+            }
+        };
+
+        // ---- pass 1: log-sum-exp of +l_w (both passes) and of -l_w (imputation weights)
+        Lse lq, lp, ln;
+        float sum_ree = 0.f, sum_req = 0.f;
+        float riv[T], hq2[T], dn[T], mix[T], rivp[T], hp2[T];
+        for (int k = 0; k < K; ++k) {
+            float lwq, lwp = 0.f, req, ree = 0.f, z, e;
+            terms(k, lwq, lwp, req, ree, riv, hq2, dn, mix, rivp, hp2, z, e);
+            lq.add(lwq); ln.add(-lwq);
+            if (REG) { lp.add(lwp); sum_ree += ree; }
+            sum_req += req;
+        }
+        const float lse_q = lq.value(), lse_p = REG ? lp.value() : 0.f, lse_n = ln.value();
+        if (lane == 0) {
+            double* rs = a.rowstat + (long)b * NM_STATS;
+            rs[0] = lse_q; rs[1] = lse_p; rs[2] = sum_ree; rs[3] = klel; rs[4] = sum_req;
+        }
+        if (!grad && !a.xm_imp) continue;
+
+        // ---- pass 2: softmax weights x element derivatives
+        float imp[T], dmu = 0.f, dlv = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) imp[t] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float lwq, lwp = 0.f, req, ree = 0.f, z = 0.f, e = 0.f;
+            terms(k, lwq, lwp, req, ree, riv, hq2, dn, mix, rivp, hp2, z, e);
+            const long row = (long)b * K + k;
+            if (a.xm_imp) {
+                const float wi = expf(-lwq - lse_n);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int j = lane + 64 * t;
+                    if (j < d) imp[t] += wi * a.xm_q[row * a.ld_q + j];
+                }
+            }
+            if (!grad) continue;
+            const float wq = a.oq * expf(lwq - lse_q);
+            const float wp = REG ? a.op * expf(lwp - lse_p) : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = lane + 64 * t;
+                if (j >= d) continue;
+                const float ee = REG ? a.oe * m[t] * (1.f - mp[t]) : 0.f;
+                a.g_xm_q[row * a.ldg_q + j] = wq * (-m[t] * riv[t] - dn[t] * sp[t] * (1.f - m[t])) - ee * riv[t];
+                a.g_xl_q[row * a.ldg_q + j] = (wq * m[t] + ee) * hq2[t];
+                gW[t] -= wq * dn[t] * sg[t] * (mix[t] - bj[t]);
+                gB[t] += wq * dn[t] * sp[t];
+                if (REG) {
+                    a.g_xm_p[row * a.ldg_p + j] = -wp * mp[t] * rivp[t];
+                    a.g_xl_p[row * a.ldg_p + j] = wp * mp[t] * hp2[t];
+                }
+            }
+            if (!REG) { dmu += wq * z; dlv += wq * (-0.5f + 0.5f * z * e * sd_q); }
+        }
+        if (a.xm_imp) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = lane + 64 * t;
+                if (j < d) a.xm_imp[(long)b * d + j] = imp[t];
+            }
+        }
+        if (grad && !REG && lok) {
+            a.g_hq[(long)b * a.ldgh + lane] = dmu;
+            a.g_hq[(long)b * a.ldgh + L + lane] = dlv;
+        }
+    }
+    if (grad) {
+        float* P = a.gwb_part + (long)gwave * 2 * d;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            if (j < d) { P[j] = gW[t]; P[d + j] = gB[t]; }
+        }
+    }
+}
+
+struct NMFinArgs {
+    const double* rowstat; const float* gwb_part; int n_waves;
+    int B, K, d, L; double alpha; int reg;
+    double* out;            // [8]: loss, loss_q, loss_p, KL_reg, NLL_E, RE_q mean, sum lse_q, sum lse_p
+    float* gW; float* gb;   // [d] each (nullptr: skip)
+    int accumulate;
+    double inv_B;           // 1 / (rows the means run over): B, or the global batch under data parallelism
+};
+__global__ __launch_bounds__(256) void nm_finalize_kernel(NMFinArgs a) {
+    __shared__ double red[256][NM_STATS];
+    double s[NM_STATS] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < a.B; b += 256)
+        for (int i = 0; i < NM_STATS; ++i) s[i] += a.rowstat[(long)b * NM_STATS + i];
+    for (int i = 0; i < NM_STATS; ++i) red[threadIdx.x][i] = s[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int i = 0; i < NM_STATS; ++i) red[threadIdx.x][i] += red[threadIdx.x + o][i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double logK = log((double)a.K);
+        const double loss_q = red[0][0] * a.inv_B - logK * (a.B * a.inv_B);
+        const double loss_p = a.reg ? red[0][1] * a.inv_B - logK * (a.B * a.inv_B) : 0.0;
+        const double nll_e = red[0][2] * a.inv_B / a.K;
+        const double kl_reg = red[0][3] * a.inv_B / a.L;
+        a.out[0] = a.reg ? loss_q + a.alpha * (kl_reg - loss_q + loss_p + nll_e) : loss_q;
+        a.out[1] = loss_q; a.out[2] = loss_p; a.out[3] = kl_reg; a.out[4] = nll_e;
+        a.out[5] = red[0][4] * a.inv_B / a.K;
+        a.out[6] = red[0][0]; a.out[7] = red[0][1];
+    }
+    if (a.gW) {
+        for (int j = threadIdx.x; j < 2 * a.d; j += 256) {
+            float acc = 0.f;
+            for (int w = 0; w < a.n_waves; ++w) acc += a.gwb_part[(long)w * 2 * a.d + j];
+            float* dst = j < a.d ? a.gW + j : a.gb + (j - a.d);
+            *dst = a.accumulate ? *dst + acc : acc;
+        }
+    }
+}
+
+// z[b,k,l] = mean[b,l] + eps[b,k,l] * exp(logvar[b,l] / 2)
+__global__ void nm_sample_kernel(const float* __restrict__ heads, long ldh, const float* __restrict__ eps,
+                                 float* __restrict__ z, long ldz, long B, int K, int L) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = B * K * L;
+    if (i >= n) return;
+    const int l = (int)(i % L);
+    const long row = i / L, b = row / K;
+    const float mu = heads[b * ldh + l], lv = heads[b * ldh + L + l];
+    z[row * ldz + l] = eps ? mu + eps[i] * expf(0.5f * lv) : mu;
+}
+// d heads[b] = g_heads[b] + ( sum_k dz[b,k,:] | sum_k dz[b,k,:] * eps * exp(logvar/2) / 2 )
+__global__ void nm_sample_bwd_kernel(const float* __restrict__ dz, long lddz, const float* __restrict__ eps,
+                                     const float* __restrict__ heads, long ldh, const float* __restrict__ g_heads,
+                                     long ldg, float* __restrict__ out, long ldo, long B, int K, int L) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int l = (int)(i % L);
+    const long b = i / L;
+    const float hs = 0.5f * expf(0.5f * heads[b * ldh + L + l]);
+    float sm = 0.f, sl = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float g = dz[(b * K + k) * lddz + l];
+        sm += g;
+        if (eps) sl += g * eps[(b * K + k) * L + l] * hs;
+    }
+    out[b * ldo + l] = sm + (g_heads ? g_heads[b * ldg + l] : 0.f);
+    out[b * ldo + L + l] = sl + (g_heads ? g_heads[b * ldg + L + l] : 0.f);
+}
+// out = x * mask  (encoder input, VAE.py:2379 / :2750)
+__global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ o, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = x[i] * m[i];
+}
+
+template <int T>
+static int launch_loss(const NMLossArgs& a, int reg, int n_blocks, hipStream_t st) {
+    const size_t lds = 3 * (size_t)a.d * sizeof(float);
+    if (reg) hipLaunchKernelGGL((nm_loss_kernel<T, true>), dim3(n_blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((nm_loss_kernel<T, false>), dim3(n_blocks), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+extern "C" {
+
+int vpc_nm_loss_blocks(long B) {
+    long blocks = (B + 3) / 4;
+    const long cap = 8L * num_cus();
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+long vpc_nm_loss_scratch(long B, int d) {  // bytes: rowstat doubles + per-wave dW/db partials + 8 output doubles
+    if (B <= 0 || d <= 0) return 0;
+    const long waves = 4L * vpc_nm_loss_blocks(B);
+    return B * NM_STATS * 8 + 64 + waves * 2 * d * 4;
+}
+
+int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const float* xm_q, const float* xl_q, long ld_q,
+                const float* xm_p, const float* xl_p, long ld_p, const float* heads_q, const float* heads_p, long ldh,
+                const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
+                float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
+                float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8, long B,
+                long B_global, int K, int d, int L, double alpha, void* stream) {
+    const int reg = mask_p != nullptr;
+    if (!x || !mask || !xm_q || !xl_q || !heads_q || !W || !b || !scratch || !out8) return VPC_ERR_ARG;
+    if (B <= 0 || K <= 0 || B * (long)K > 0x7fffff00L || B_global < B) return VPC_ERR_ARG;
+    if (d <= 0 || d > 256 || L <= 0 || L > 64) return VPC_ERR_SHAPE;
+    if (reg && (!xm_p || !xl_p || !heads_p)) return VPC_ERR_ARG;
+    if (!reg && !eps_kl) return VPC_ERR_ARG;
+    const bool grad = g_xm_q != nullptr;
+    if (grad && (!g_xl_q || !g_heads_q || !gW || !gb || (reg && (!g_xm_p || !g_xl_p || !g_heads_p)))) return VPC_ERR_ARG;
+    if (scratch_bytes < vpc_nm_loss_scratch(B, d) || (reinterpret_cast<uintptr_t>(scratch) & 7)) return VPC_ERR_ARG;
+    const int blocks = vpc_nm_loss_blocks(B);
+    NMLossArgs a{};
+    a.x = x; a.m = mask; a.mp = mask_p; a.xm_q = xm_q; a.xl_q = xl_q; a.ld_q = ld_q; a.xm_p = xm_p; a.xl_p = xl_p;
+    a.ld_p = ld_p; a.hq = heads_q; a.hp = heads_p; a.ldh = ldh; a.W = W; a.b = b; a.eps_kl = eps_kl;
+    a.g_xm_q = g_xm_q; a.g_xl_q = g_xl_q; a.ldg_q = ldg_q; a.g_xm_p = g_xm_p; a.g_xl_p = g_xl_p; a.ldg_p = ldg_p;
+    a.g_hq = g_heads_q; a.g_hp = g_heads_p; a.ldgh = ldgh; a.xm_imp = xm_imp;
+    a.rowstat = reinterpret_cast<double*>(scratch);
+    a.gwb_part = reinterpret_cast<float*>(a.rowstat + B * NM_STATS + 8);
+    a.B = (int)B; a.K = K; a.d = d; a.L = L;
+    const double al = reg ? alpha : 0.0, Bg = (double)B_global;
+    a.oq = (float)((1.0 - al) / Bg); a.op = (float)(al / Bg); a.oe = (float)(al / (Bg * K)); a.cr = (float)(al / (Bg * L));
+    a.kq = a.oq; a.kp = a.op;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = d <= 64 ? launch_loss<1>(a, reg, blocks, st) : d <= 128 ? launch_loss<2>(a, reg, blocks, st)
+                                                                      : launch_loss<4>(a, reg, blocks, st);
+    if (rc != VPC_OK) return rc;
+    NMFinArgs f{};
+    f.rowstat = a.rowstat; f.gwb_part = a.gwb_part; f.n_waves = 4 * blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;
+    f.alpha = al; f.reg = reg; f.out = out8; f.gW = grad ? gW : nullptr; f.gb = gb; f.accumulate = accumulate_wb;
+    f.inv_B = 1.0 / Bg;
+    hipLaunchKernelGGL(nm_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+int vpc_nm_sample(const float* heads, long ldh, const float* eps, float* z, long ldz, long B, int K, int L,
+                  void* stream) {
+    if (!heads || !z || B <= 0 || K <= 0 || L <= 0 || ldh < 2 * L || ldz < L) return VPC_ERR_ARG;
+    const long n = B * K * L;
+    hipLaunchKernelGGL(nm_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, heads,
+                       ldh, eps, z, ldz, B, K, L);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+int vpc_nm_sample_bwd(const float* dz, long lddz, const float* eps, const float* heads, long ldh, const float* g_heads,
+                      long ldg, float* out, long ldo, long B, int K, int L, void* stream) {
+    if (!dz || !heads || !out || B <= 0 || K <= 0 || L <= 0 || lddz < L || ldh < 2 * L || ldo < 2 * L)
+        return VPC_ERR_ARG;
+    const long n = B * L;
+    hipLaunchKernelGGL(nm_sample_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz,
+                       lddz, eps, heads, ldh, g_heads, ldg, out, ldo, B, K, L);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+int vpc_nm_mul(const float* x, const float* mask, float* out, long n, void* stream) {
+    if (!x || !mask || !out || n <= 0) return VPC_ERR_ARG;
+    hipLaunchKernelGGL(nm_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask,
+                       out, n);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+"""MNAR path (BASELINE config 3): drop-in classes for the reference's
+
+    REG_notMIWAE_v2      src/models/VAE.py:2327-2505
+    notMIWAE_myversion   src/models/VAE.py:2691-2847
+
+with the same constructor arguments, `encoder` / `decoder` / `forward` / `loss` signatures, return order and
+state_dict keys (W, b, seq_encoder.{0,2}, q_mu.0, q_logstd.0, seq_decoder.{0,2}, x_mean.0, x_logvar.0 and, for the
+regularised class, the unused float64 `logits.0`).  Every layer runs as an fp32 MFMA GEMM (csrc/vpc_gemm.hip), the
+importance-weighted loss with the self-masking missingness model and all of its gradients in one fused kernel
+(csrc/vpc_nm.hip).  The two heads of the encoder (q_mu | q_logstd) and of the decoder (x_mean | x_logvar) are
+adjacent in one flat parameter buffer, so each pair is ONE GEMM.  No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from ._lib import check, lib, ptr, require_cuda, stream_ptr
+
+HID = 128  # VAE.py:2343-2363 hard-codes 128 (hid_dim is ignored by the reference too)
+ACT_NONE, ACT_ELU, ACT_SIGMOID_HARDTANH, ACT_RELU = 0, 1, 2, 3
+
+
+# ------------------------------------------------------------------------------------------------ raw ops
+def linear_fwd(x, w, b, y, M, N, K, act=ACT_NONE, split=0, ldx=None, ldy=None):
+    check(lib().vpc_linear_fwd(ptr(x), ldx or K, ptr(w), ptr(b), ptr(y), ldy or N, M, N, K, act, split, stream_ptr()),
+          "vpc_linear_fwd")
+
+
+def linear_dgrad(dy, w, dx, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=0, x_out=None, act_prev=ACT_NONE,
+                 lddy=None, lddx=None):
+    check(lib().vpc_linear_dgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(w), ptr(x_out), K,
+                                 act_prev, ptr(dx), lddx or K, M, N, K, stream_ptr()), "vpc_linear_dgrad")
+
+
+_scratch = {}
+
+
+def _wgrad_scratch(device, floats):
+    key = str(device)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(floats, 1 << 20), device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def linear_wgrad(dy, x, dw, db, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=0, accumulate=False, lddy=None,
+                 ldx=None):
+    need = int(lib().vpc_linear_wgrad_scratch(M, N, K))
+    sc = _wgrad_scratch(dy.device, need)
+    check(lib().vpc_linear_wgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(x), ldx or K,
+                                 ptr(dw), ptr(db), ptr(sc), sc.numel(), M, N, K, int(accumulate), stream_ptr()),
+          "vpc_linear_wgrad")
+
+
+def nm_sample(heads, eps, z, B, K, Ld):
+    check(lib().vpc_nm_sample(ptr(heads), 2 * Ld, ptr(eps), ptr(z), Ld, B, K, Ld, stream_ptr()), "vpc_nm_sample")
+
+
+def nm_sample_bwd(dz, eps, heads, g_heads, out, B, K, Ld):
+    check(lib().vpc_nm_sample_bwd(ptr(dz), Ld, ptr(eps), ptr(heads), 2 * Ld, ptr(g_heads), 2 * Ld, ptr(out), 2 * Ld, B,
+                                  K, Ld, stream_ptr()), "vpc_nm_sample_bwd")
+
+
+def nm_mul(x, mask, out):
+    check(lib().vpc_nm_mul(ptr(x), ptr(mask), ptr(out), out.numel(), stream_ptr()), "vpc_nm_mul")
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _rows_view(t, B, K, d):
+    """[B, K, d] tensor -> (tensor to pass, row pitch) without copying when rows b*K+k are equally spaced."""
+    if t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == K * t.stride(1) \
+            and t.stride(1) >= d:
+        return t, t.stride(1)
+    t = _f32c(t).reshape(B, K, d)
+    return t, d
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+class NMEncoderFn(torch.autograd.Function):
+    """(x, mask, eps) -> (z [B,K,L], heads [B, mean L | logvar L]).  VAE.py:2378-2391 / :2749-2765."""
+
+    @staticmethod
+    def forward(ctx, model, x, mask, eps, K, *weights):
+        require_cuda(x, mask, eps, *weights)
+        v = model._views()
+        d, Ld = model.obs_dim, model.latent_dim
+        B, dev = x.shape[0], x.device
+        xin = torch.empty(B, d, device=dev)
+        nm_mul(x, mask, xin)
+        h1 = torch.empty(B, HID, device=dev)
+        h2 = torch.empty(B, HID, device=dev)
+        heads = torch.empty(B, 2 * Ld, device=dev)
+        linear_fwd(xin, v["We1"], v["be1"], h1, B, HID, d, ACT_ELU)
+        linear_fwd(h1, v["We2"], v["be2"], h2, B, HID, HID, ACT_ELU)
+        linear_fwd(h2, v["Wh"], v["bh"], heads, B, 2 * Ld, HID, ACT_NONE)
+        z = torch.empty(B * K, Ld, device=dev)
+        nm_sample(heads, eps, z, B, K, Ld)
+        ctx.model, ctx.K = model, K
+        ctx.save_for_backward(xin, h1, h2, heads, eps if eps is not None else torch.empty(0, device=dev))
+        ctx.has_eps = eps is not None
+        return z.view(B, K, Ld), heads
+
+    @staticmethod
+    def backward(ctx, dz, dheads):
+        model, K = ctx.model, ctx.K
+        xin, h1, h2, heads, eps = ctx.saved_tensors
+        eps = eps if ctx.has_eps else None
+        v = model._views()
+        d, Ld = model.obs_dim, model.latent_dim
+        B, dev = xin.shape[0], xin.device
+        dht = torch.empty(B, 2 * Ld, device=dev)
+        nm_sample_bwd(_f32c(dz).reshape(B * K, Ld), eps, heads, _f32c(dheads), dht, B, K, Ld)
+        g = model._grad_views(torch.empty(model._n_enc, device=dev), "enc")
+        dh2 = torch.empty(B, HID, device=dev)
+        dh1 = torch.empty(B, HID, device=dev)
+        linear_wgrad(dht, h2, g["Wh"], g["bh"], B, 2 * Ld, HID)
+        linear_dgrad(dht, v["Wh"], dh2, B, 2 * Ld, HID, x_out=h2, act_prev=ACT_ELU)
+        linear_wgrad(dh2, h1, g["We2"], g["be2"], B, HID, HID)
+        linear_dgrad(dh2, v["We2"], dh1, B, HID, HID, x_out=h1, act_prev=ACT_ELU)
+        linear_wgrad(dh1, xin, g["We1"], g["be1"], B, HID, d)
+        return (None, None, None, None, None, g["We1"], g["be1"], g["We2"], g["be2"], g["Wmu"], g["bmu"], g["Wls"],
+                g["bls"])
+
+
+class NMDecoderFn(torch.autograd.Function):
+    """z [.., L] -> (x_mean, x_logvar) as the two halves of ONE [M, 2d] buffer.  VAE.py:2393-2397 / :2767-2772."""
+
+    @staticmethod
+    def forward(ctx, model, z, *weights):
+        require_cuda(z, *weights)
+        v = model._views()
+        d, Ld = model.obs_dim, model.latent_dim
+        lead = z.shape[:-1]
+        z2 = _f32c(z).reshape(-1, Ld)
+        M, dev = z2.shape[0], z2.device
+        g1 = torch.empty(M, HID, device=dev)
+        g2 = torch.empty(M, HID, device=dev)
+        Y = torch.empty(M, 2 * d, device=dev)
+        linear_fwd(z2, v["Wd1"], v["bd1"], g1, M, HID, Ld, ACT_ELU)
+        linear_fwd(g1, v["Wd2"], v["bd2"], g2, M, HID, HID, ACT_ELU)
+        linear_fwd(g2, v["Wx"], v["bx"], Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d)
+        ctx.model, ctx.lead = model, lead
+        ctx.save_for_backward(z2, g1, g2, Y)
+        Y3 = Y.view(*lead, 2 * d)
+        return Y3[..., :d], Y3[..., d:]
+
+    @staticmethod
+    def backward(ctx, gxm, gxl):
+        model = ctx.model
+        z2, g1, g2, Y = ctx.saved_tensors
+        v = model._views()
+        d, Ld = model.obs_dim, model.latent_dim
+        M, dev = z2.shape[0], z2.device
+        # the fused loss hands back the two halves of one [M, 2d] buffer: use it in place
+        G = None
+        if (gxm.dtype == torch.float32 and gxl.dtype == torch.float32 and gxm.dim() >= 2
+                and gxm.stride() == gxl.stride() and gxm.stride(-1) == 1 and gxm.stride(-2) == 2 * d
+                and gxl.data_ptr() == gxm.data_ptr() + 4 * d
+                and all(gxm.stride(i) == gxm.stride(i + 1) * gxm.shape[i + 1] for i in range(gxm.dim() - 2))):
+            G = gxm.as_strided((M, 2 * d), (2 * d, 1))
+        if G is None:
+            G = torch.cat([_f32c(gxm).reshape(M, d), _f32c(gxl).reshape(M, d)], 1)
+        g = model._grad_views(torch.empty(model._n_dec, device=dev), "dec")
+        dg2 = torch.empty(M, HID, device=dev)
+        dg1 = torch.empty(M, HID, device=dev)
+        dz = torch.empty(M, Ld, device=dev)
+        linear_wgrad(G, g2, g["Wx"], g["bx"], M, 2 * d, HID, y_gate=Y, gate=ACT_SIGMOID_HARDTANH, gate_split=d)
+        linear_dgrad(G, v["Wx"], dg2, M, 2 * d, HID, y_gate=Y, gate=ACT_SIGMOID_HARDTANH, gate_split=d, x_out=g2,
+                     act_prev=ACT_ELU)
+        linear_wgrad(dg2, g1, g["Wd2"], g["bd2"], M, HID, HID)
+        linear_dgrad(dg2, v["Wd2"], dg1, M, HID, HID, x_out=g1, act_prev=ACT_ELU)
+        linear_wgrad(dg1, z2, g["Wd1"], g["bd1"], M, HID, Ld)
+        linear_dgrad(dg1, v["Wd1"], dz, M, HID, Ld)
+        return (None, dz.view(*ctx.lead, Ld), g["Wd1"], g["bd1"], g["Wd2"], g["bd2"], g["Wxm"], g["bxm"], g["Wxl"],
+                g["bxl"])
+
+
+class NMLossFn(torch.autograd.Function):
+    """Fused importance-weighted loss + every gradient.  Returns (loss fp32, out8 fp64, xm_imp or empty)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, mask, mask_p, xm_q, xl_q, heads_q, xm_p, xl_p, heads_p, W, b, eps_kl):
+        reg = mask_p is not None
+        require_cuda(x, mask, mask_p, xm_q, xl_q, heads_q, xm_p, xl_p, heads_p, W, b, eps_kl)
+        B, K, d, Ld = cfg["B"], cfg["K"], cfg["d"], cfg["L"]
+        dev = x.device
+        xm_q, ldq = _rows_view(xm_q, B, K, d)
+        xl_q, ldq2 = _rows_view(xl_q, B, K, d)
+        if ldq2 != ldq:
+            xm_q, xl_q = xm_q.contiguous(), xl_q.contiguous()
+            ldq = d
+        ldp = d
+        if reg:
+            xm_p, ldp = _rows_view(xm_p, B, K, d)
+            xl_p, ldp2 = _rows_view(xl_p, B, K, d)
+            if ldp2 != ldp:
+                xm_p, xl_p = xm_p.contiguous(), xl_p.contiguous()
+                ldp = d
+        heads_q = _f32c(heads_q)
+        heads_p = _f32c(heads_p) if reg else None
+        need_grad = cfg["grad"] and any(ctx.needs_input_grad)
+        Gq = Gp = ghq = ghp = gW = gb = None
+        if need_grad:
+            Gq = torch.empty(B * K, 2 * d, device=dev)
+            ghq = torch.empty(B, 2 * Ld, device=dev)
+            gW = torch.empty(d, device=dev)
+            gb = torch.empty(d, device=dev)
+            if reg:
+                Gp = torch.empty(B * K, 2 * d, device=dev)
+                ghp = torch.empty(B, 2 * Ld, device=dev)
+        xm_imp = torch.empty(B, d, device=dev) if cfg["impute"] else None
+        nbytes = int(lib().vpc_nm_loss_scratch(B, d))
+        scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+        out8 = torch.empty(8, dtype=torch.float64, device=dev)
+        half = lambda G: None if G is None else G[:, d:]
+        check(lib().vpc_nm_loss(ptr(x), ptr(mask), ptr(mask_p), ptr(xm_q), ptr(xl_q), ldq, ptr(xm_p), ptr(xl_p), ldp,
+                                ptr(heads_q), ptr(heads_p), 2 * Ld, ptr(W), ptr(b), ptr(eps_kl), ptr(Gq), ptr(half(Gq)),
+                                2 * d, ptr(Gp), ptr(half(Gp)), 2 * d, ptr(ghq), ptr(ghp), 2 * Ld, ptr(gW), ptr(gb), 0,
+                                ptr(xm_imp), ptr(scratch), scratch.numel() * 8, ptr(out8), B, cfg.get("B_global", B), K,
+                                d, Ld, float(cfg["alpha"]), stream_ptr()), "vpc_nm_loss")
+        ctx.reg, ctx.need_grad, ctx.dims = reg, need_grad, (B, K, d, Ld)
+        ctx.wshape = W.shape
+        if need_grad:
+            ctx.save_for_backward(*[t for t in (Gq, ghq, gW, gb, Gp, ghp) if t is not None])
+        loss = out8[0].float()
+        imp = xm_imp if xm_imp is not None else torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(out8, imp)
+        return loss, out8, imp
+
+    @staticmethod
+    def backward(ctx, gloss, _g8, _gi):
+        if not ctx.need_grad:
+            return (None,) * 13
+        B, K, d, Ld = ctx.dims
+        t = ctx.saved_tensors
+        Gq, ghq, gW, gb = t[:4]
+        Gq, ghq, gW, gb = Gq * gloss, ghq * gloss, gW * gloss, gb * gloss
+        Gq3 = Gq.view(B, K, 2 * d)
+        gWs, gbs = gW.view(ctx.wshape), gb.view(ctx.wshape)
+        if ctx.reg:
+            Gp, ghp = t[4] * gloss, t[5] * gloss
+            Gp3 = Gp.view(B, K, 2 * d)
+            return (None, None, None, None, Gq3[..., :d], Gq3[..., d:], ghq, Gp3[..., :d], Gp3[..., d:], ghp, gWs, gbs,
+                    None)
+        return None, None, None, None, Gq3[..., :d], Gq3[..., d:], ghq, None, None, None, gWs, gbs, None
+
+
+# ------------------------------------------------------------------------------------------------ model classes
+class _NMBase(nn.Module):
+    regularised = False
+
+    def __init__(self, obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates):
+        super().__init__()
+        if obs_dim > 256 or latent_dim > 64:
+            raise L.VpcError("the MNAR-path kernels support obs_dim <= 256 and latent_dim <= 64")
+        self.obs_dim = obs_dim
+        self.hid_dim = hid_dim
+        self.emb_dim = 10
+        self.num_samples = num_samples
+        self.num_estimates = num_estimates
+        self.latent_dim = latent_dim
+        self.batch_size = training_parameters["batch_size"]
+        self.K = K
+        self.obs_std = 0.1
+        self.number_components = 500
+        self.training_paramters = training_parameters  # (sic) VAE.py:2341
+        d, Ld = obs_dim, latent_dim
+        # parameter containers, created in the reference's order (same seed -> same initial weights)
+        self.seq_encoder = nn.Sequential(nn.Linear(d, HID), nn.ELU(), nn.Linear(HID, HID), nn.ELU())
+        self.q_mu = nn.Sequential(nn.Linear(HID, Ld))
+        self.q_logstd = nn.Sequential(nn.Linear(HID, Ld))
+        self.seq_decoder = nn.Sequential(nn.Linear(Ld, HID), nn.ELU(), nn.Linear(HID, HID), nn.ELU())
+        self.x_mean = nn.Sequential(nn.Linear(HID, d), nn.Sigmoid())
+        self.x_logvar = nn.Sequential(nn.Linear(HID, d), nn.Hardtanh(min_val=-10.0, max_val=0))
+        emb1 = torch.empty([1, 1, d])
+        nn.init.xavier_uniform_(emb1)
+        self.W = nn.Parameter(emb1)
+        emb2 = torch.empty([1, 1, d])
+        nn.init.xavier_uniform_(emb2)
+        self.b = nn.Parameter(emb2)
+        self.activation = nn.Softplus()
+        self._flat = None
+        self._n_enc = HID * d + HID + HID * HID + HID + 2 * Ld * HID + 2 * Ld
+        self._n_dec = HID * Ld + HID + HID * HID + HID + 2 * d * HID + 2 * d
+
+    # ---- flat parameter buffer: [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]
+    def _flat_order(self):
+        se, sd = self.seq_encoder, self.seq_decoder
+        return [("W", self.W), ("b", self.b),
+                ("We1", se[0].weight), ("be1", se[0].bias), ("We2", se[2].weight), ("be2", se[2].bias),
+                ("Wmu", self.q_mu[0].weight), ("Wls", self.q_logstd[0].weight),
+                ("bmu", self.q_mu[0].bias), ("bls", self.q_logstd[0].bias),
+                ("Wd1", sd[0].weight), ("bd1", sd[0].bias), ("Wd2", sd[2].weight), ("bd2", sd[2].bias),
+                ("Wxm", self.x_mean[0].weight), ("Wxl", self.x_logvar[0].weight),
+                ("bxm", self.x_mean[0].bias), ("bxl", self.x_logvar[0].bias)]
+
+    def trainable(self):
+        """The 18 trainable tensors in flat-buffer order."""
+        return [p for _, p in self._flat_order()]
+
+    def flatten_parameters(self):
+        """Make the 18 trainable tensors views of ONE flat fp32 buffer.  Idempotent; call again after .to()."""
+        order = self._flat_order()
+        flat = self._flat
+        ok = flat is not None and flat.device == order[0][1].device
+        off = 0
+        if ok:
+            for _, p in order:
+                if p.data.data_ptr() != flat.data_ptr() + 4 * off or not p.data.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            flat = torch.cat([p.data.detach().reshape(-1).float() for _, p in order]).contiguous()
+            off = 0
+            for _, p in order:
+                p.data = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self._flat = flat
+            self._view_cache = None
+        return self._flat
+
+    def _segment_views(self, buf, which):
+        """Named views into a buffer laid out like the 'wb' / 'enc' / 'dec' segment of the flat buffer."""
+        d, Ld = self.obs_dim, self.latent_dim
+        spec = {"wb": [("W", (d,)), ("b", (d,))],
+                "enc": [("We1", (HID, d)), ("be1", (HID,)), ("We2", (HID, HID)), ("be2", (HID,)), ("Wmu", (Ld, HID)),
+                        ("Wls", (Ld, HID)), ("bmu", (Ld,)), ("bls", (Ld,))],
+                "dec": [("Wd1", (HID, Ld)), ("bd1", (HID,)), ("Wd2", (HID, HID)), ("bd2", (HID,)), ("Wxm", (d, HID)),
+                        ("Wxl", (d, HID)), ("bxm", (d,)), ("bxl", (d,))]}[which]
+        out, off = {}, 0
+        for name, shp in spec:
+            n = math.prod(shp)
+            out[name] = buf[off:off + n].view(shp)
+            off += n
+        if which == "enc":
+            o = out["Wmu"].storage_offset() - buf.storage_offset()
+            out["Wh"] = buf[o:o + 2 * Ld * HID].view(2 * Ld, HID)
+            o += 2 * Ld * HID
+            out["bh"] = buf[o:o + 2 * Ld]
+        elif which == "dec":
+            o = out["Wxm"].storage_offset() - buf.storage_offset()
+            out["Wx"] = buf[o:o + 2 * d * HID].view(2 * d, HID)
+            o += 2 * d * HID
+            out["bx"] = buf[o:o + 2 * d]
+        return out
+
+    def _views(self):
+        flat = self.flatten_parameters()
+        L.require_cuda(flat)
+        if getattr(self, "_view_cache", None) is None or self._view_cache[0] is not flat:
+            d = self.obs_dim
+            v = self._segment_views(flat[:2 * d], "wb")
+            v.update(self._segment_views(flat[2 * d:2 * d + self._n_enc], "enc"))
+            v.update(self._segment_views(flat[2 * d + self._n_enc:], "dec"))
+            self._view_cache = (flat, v)
+        return self._view_cache[1]
+
+    def _grad_views(self, buf, which):
+        return self._segment_views(buf, which)
+
+    def _enc_weights(self):
+        se = self.seq_encoder
+        return (se[0].weight, se[0].bias, se[2].weight, se[2].bias, self.q_mu[0].weight, self.q_mu[0].bias,
+                self.q_logstd[0].weight, self.q_logstd[0].bias)
+
+    def _dec_weights(self):
+        sd = self.seq_decoder
+        return (sd[0].weight, sd[0].bias, sd[2].weight, sd[2].bias, self.x_mean[0].weight, self.x_mean[0].bias,
+                self.x_logvar[0].weight, self.x_logvar[0].bias)
+
+    # ---- reference API
+    def _encode(self, x, mask, sample=True, eps=None):
+        L.require_cuda(x)
+        d, Ld, K = self.obs_dim, self.latent_dim, self.num_samples
+        xf = _f32c(x.reshape(-1, d))
+        mf = _f32c(mask.reshape(-1, d).to(x.device))
+        B = xf.shape[0]
+        if sample and eps is None:
+            eps = torch.randn(B, K, Ld, device=xf.device)  # Normal(mean, std).rsample(), VAE.py:2387 / :2761
+        z, heads = NMEncoderFn.apply(self, xf, mf, _f32c(eps) if sample else None, K, *self._enc_weights())
+        mean = heads[:, :Ld].unsqueeze(1).expand(B, K, Ld)
+        log_var = heads[:, Ld:].unsqueeze(1).expand(B, K, Ld)
+        mean._vpc_heads = heads
+        log_var._vpc_heads = heads
+        return z, mean, log_var
+
+    def encoder(self, x, mask, sample=True):
+        """VAE.py:2378-2391 / :2749-2765 -> (z, mean, log_var), each [B, num_samples, latent_dim]."""
+        return self._encode(x, mask, sample)
+
+    def decoder(self, z_int):
+        """VAE.py:2393-2397 / :2767-2772 -> (x_mean, x_logvar)."""
+        L.require_cuda(z_int)
+        return NMDecoderFn.apply(self, z_int, *self._dec_weights())
+
+    @staticmethod
+    def _heads_of(mean, logvar):
+        h = getattr(mean, "_vpc_heads", None)
+        if h is not None and h is getattr(logvar, "_vpc_heads", None):
+            return h
+        return torch.cat([mean[:, 0, :], logvar[:, 0, :]], 1)  # any [B,K,L] pair replicated over K
+
+    def _loss(self, x, mask, mask_p, outs_q, outs_p, alpha, eps_kl, llh_eval):
+        d, Ld, K = self.obs_dim, self.latent_dim, self.num_samples
+        xf = _f32c(x.reshape(-1, d))
+        B = xf.shape[0]
+        cfg = dict(B=B, K=K, d=d, L=Ld, alpha=alpha, grad=torch.is_grad_enabled(), impute=bool(llh_eval))
+        xm_q, xl_q, mean_q, logvar_q = outs_q
+        hq = self._heads_of(mean_q, logvar_q)
+        mf = _f32c(mask.reshape(-1, d).to(xf.device))
+        if outs_p is not None:
+            xm_p, xl_p, mean_p, logvar_p = outs_p
+            hp = self._heads_of(mean_p, logvar_p)
+            mpf = _f32c(mask_p.reshape(-1, d).to(xf.device))
+        else:
+            xm_p = xl_p = hp = mpf = None
+        loss, out8, imp = NMLossFn.apply(cfg, xf, mf, mpf, xm_q, xl_q, hq, xm_p, xl_p, hp, self.W, self.b, eps_kl)
+        if llh_eval:  # VAE.py:2458-2461 / :2810-2813
+            return imp, loss, out8[5].float()
+        return loss, loss  # (print_loss, train_loss)
+
+
+class REG_notMIWAE_v2(_NMBase):
+    """Posterior-consistency regularised not-MIWAE.  Reference: src/models/VAE.py:2327-2505."""
+    regularised = True
+
+    def __init__(self, obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates):
+        super().__init__(obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates)
+        self.logits = nn.Sequential(nn.Linear(obs_dim, obs_dim)).double()  # VAE.py:2371: unused, but in state_dict
+        self.max_epoch = 2800
+
+    def forward(self, data, mask, mask_p, stage="train"):
+        # VAE.py:2500-2505: q pass first (RNG order), p outputs returned first
+        z_q, mean_q, logvar_q = self.encoder(data, mask)
+        x_mean_q, x_logvar_q = self.decoder(z_q)
+        z_p, mean_p, logvar_p = self.encoder(data, mask_p)
+        x_mean_p, x_logvar_p = self.decoder(z_p)
+        return mean_p, logvar_p, x_mean_p, x_logvar_p, mean_q, logvar_q, x_mean_q, x_logvar_q
+
+    def loss(self, x, x_recon_p, x_logvar_p, mean_p, logvar_p, x_recon_q, x_logvar_q, mean_q, logvar_q, mask, mask_p,
+             epoch, vae_elbo=False, llh_eval=False, MI=False, beta_annealing=False, beta=1.0, alpha=1.0,
+             alpha_annealing=False, stage="train", missing_process="selfmasking_known"):
+        """VAE.py:2398-2471.  epoch / beta / annealing flags are accepted and, as in the reference, unused."""
+        if missing_process != "selfmasking_known":
+            raise NotImplementedError("only the reference's default missing_process='selfmasking_known' is accelerated")
+        if MI:
+            raise NotImplementedError("the MI branch of the reference reads undefined names (VAE.py:2463-2467)")
+        return self._loss(x, mask, mask_p, (x_recon_q, x_logvar_q, mean_q, logvar_q),
+                          (x_recon_p, x_logvar_p, mean_p, logvar_p), alpha, None, llh_eval)
+
+
+class notMIWAE_myversion(_NMBase):
+    """not-MIWAE with a Monte-Carlo KL.  Reference: src/models/VAE.py:2691-2847."""
+
+    def forward(self, data, mask, stage="train"):
+        z, mean, logvar = self.encoder(data, mask)
+        x_mean, x_logvar = self.decoder(z)
+        return mean, logvar, x_mean, x_logvar
+
+    def loss(self, x, x_recon, x_logvar, mean, logvar, epoch, mask, vae_elbo=False, llh_eval=False, MI=False,
+             beta_annealing=False, beta=1.0, stage="train", missing_process="selfmasking_known", eps_kl=None):
+        """VAE.py:2774-2823; draws the fresh z of :2791-2793 on the device unless eps_kl [B,K,L] is given."""
+        if missing_process != "selfmasking_known":
+            raise NotImplementedError("only the reference's default missing_process='selfmasking_known' is accelerated")
+        if MI:
+            raise NotImplementedError("the MI branch of the reference reads undefined names (VAE.py:2815-2819)")
+        B = x.reshape(-1, self.obs_dim).shape[0]
+        if eps_kl is None:
+            eps_kl = torch.randn(B, self.num_samples, self.latent_dim, device=x.device)
+        return self._loss(x, mask, None, (x_recon, x_logvar, mean, logvar), None, 0.0, _f32c(eps_kl), llh_eval)
