@@ -246,3 +246,50 @@ def test_cpu_tensors_raise(nm):
     model = nm.notMIWAE_myversion(14, 500, 10, 10, {"batch_size": 8, "patience": 1}, 4, 1)
     with pytest.raises(vpc_amd.VpcError):
         model.forward(torch.rand(8, 14), torch.ones(8, 14))
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_fused_trainer_trajectory(nm, kind):
+    """NMTrainer (stacked q/p GEMMs, flat grads, flat Adam) reproduces the reference's 5-step trajectory."""
+    g = load_golden(f"nm_traj_{kind}_d14.npz")
+    model = _load_model(nm, g, nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion, "param0.")
+    tr = nm.NMTrainer(model, lr=1e-3)
+    x, m = _dev(g["x"]), _dev(g["mask"])
+    total = 0.0
+    for s in range(len(g["losses"])):
+        tr.step(x, m, mask_p=_dev(g["mask_p"][s]) if kind == "reg" else None, eps=_dev(g["eps"][s]), alpha=0.5)
+        assert abs(tr.loss_value() - g["losses"][s]) <= 1e-4 * abs(g["losses"][s]), (s, tr.loss_value())
+        total += g["losses"][s]
+    assert abs(tr.epoch_total() - total) <= 1e-4 * abs(total)
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("param5."):
+            _close(sd[k[7:]], torch.from_numpy(v), 5e-5, k)
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_fused_trainer_device_draws(nm, kind):
+    """With on-device draws: mask_p is a sub-mask of mask with the requested keep rate, the step is bit-reproducible
+    for a fixed seed, and the loss decreases over a few steps."""
+    torch.manual_seed(0)
+    cls = nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion
+    B, d, K = 256, 128, 20
+    x = torch.rand(B, d, device="cuda")
+    m = (torch.rand(B, d, device="cuda") < 0.7).float()
+    finals = []
+    for rep in range(2):
+        torch.manual_seed(1)
+        model = cls(d, 500, 10, 10, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, lr=1e-3, seed=7)
+        losses = []
+        for s in range(6):
+            tr.step(x, m, alpha=0.5, p_missingness=50)
+            losses.append(tr.loss_value())
+        if kind == "reg":
+            mp = tr.mask_p
+            assert bool(((mp == 0) | (mp == 1)).all()) and bool((mp <= m).all())
+            keep = float(mp.sum() / m.sum())
+            assert abs(keep - 0.5) < 0.02, keep
+        assert losses[-1] < losses[0]
+        finals.append((losses, model._flat.clone()))
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])

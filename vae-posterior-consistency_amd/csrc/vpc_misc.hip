@@ -339,6 +339,28 @@ __global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __rest
     else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
 }
 
+// fused MNAR step: float mask_p draw + the stacked encoder input [x*mask ; x*mask_p]
+__global__ void nm_prep_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ mp,
+                               float* __restrict__ xin, long n, float keep_prob, uint64_t seed, uint64_t offset,
+                               const long long* __restrict__ state) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i0 = g * 4;
+    if (i0 >= n) return;
+    if (state) offset += (uint64_t)state[1];
+    U4 r{0, 0, 0, 0};
+    if (mp) r = philox((uint64_t)g + offset, 0u, seed);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    for (int j = 0; j < 4 && i0 + j < n; ++j) {
+        const float xv = x[i0 + j], mv = m[i0 + j];
+        xin[i0 + j] = xv * mv;
+        if (mp) {
+            const float pv = u01(rr[j]) < keep_prob ? mv : 0.f;
+            mp[i0 + j] = pv;
+            xin[n + i0 + j] = xv * pv;
+        }
+    }
+}
+
 }  // namespace vpc
 
 using namespace vpc;
@@ -558,5 +580,15 @@ extern "C" int vpc_fill_normal(float* out, long n, unsigned long long seed, unsi
     const long groups = (n + 3) / 4;
     hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        out, n, (uint64_t)seed, (uint64_t)offset);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin, long B, int d,
+                           float keep_prob, unsigned long long seed, unsigned long long offset, const long long* state,
+                           void* stream) {
+    if (!x || !mask || !xin || B <= 0 || d <= 0) return VPC_ERR_ARG;
+    const long n = B * d, groups = (n + 3) / 4;
+    hipLaunchKernelGGL(nm_prep_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask,
+                       mask_p_out, xin, n, keep_prob, (uint64_t)seed, (uint64_t)offset, state);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }

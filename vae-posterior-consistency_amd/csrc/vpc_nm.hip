@@ -236,6 +236,8 @@ struct NMFinArgs {
     int B, K, d, L; double alpha; int reg;
     double* out;            // [8]: loss, loss_q, loss_p, KL_reg, NLL_E, RE_q mean, sum lse_q, sum lse_p
     float* gW; float* gb;   // [d] each (nullptr: skip)
+    float* loss_f32;        // optional: out[0] as a float (slot of the data-parallel bucket)
+    float* accum;           // optional: accum[0] += loss (epoch total, train.py:117, without a host sync)
     int accumulate;
     double inv_B;           // 1 / (rows the means run over): B, or the global batch under data parallelism
 };
@@ -261,6 +263,8 @@ __global__ __launch_bounds__(256) void nm_finalize_kernel(NMFinArgs a) {
         a.out[1] = loss_q; a.out[2] = loss_p; a.out[3] = kl_reg; a.out[4] = nll_e;
         a.out[5] = red[0][4] * a.inv_B / a.K;
         a.out[6] = red[0][0]; a.out[7] = red[0][1];
+        if (a.loss_f32) a.loss_f32[0] = (float)a.out[0];
+        if (a.accum) a.accum[0] += (float)a.out[0];
     }
     if (a.gW) {
         for (int j = threadIdx.x; j < 2 * a.d; j += 256) {
@@ -338,8 +342,9 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                 const float* xm_p, const float* xl_p, long ld_p, const float* heads_q, const float* heads_p, long ldh,
                 const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
                 float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
-                float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8, long B,
-                long B_global, int K, int d, int L, double alpha, void* stream) {
+                float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8,
+                float* loss_f32, float* accum, long B, long B_global, int K, int d, int L, double alpha,
+                void* stream) {
     const int reg = mask_p != nullptr;
     if (!x || !mask || !xm_q || !xl_q || !heads_q || !W || !b || !scratch || !out8) return VPC_ERR_ARG;
     if (B <= 0 || K <= 0 || B * (long)K > 0x7fffff00L || B_global < B) return VPC_ERR_ARG;
@@ -368,6 +373,7 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
     NMFinArgs f{};
     f.rowstat = a.rowstat; f.gwb_part = a.gwb_part; f.n_waves = 4 * blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;
     f.alpha = al; f.reg = reg; f.out = out8; f.gW = grad ? gW : nullptr; f.gb = gb; f.accumulate = accumulate_wb;
+    f.loss_f32 = loss_f32; f.accum = accum;
     f.inv_B = 1.0 / Bg;
     hipLaunchKernelGGL(nm_finalize_kernel, dim3(1), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;

@@ -70,6 +70,21 @@ def nm_mul(x, mask, out):
     check(lib().vpc_nm_mul(ptr(x), ptr(mask), ptr(out), out.numel(), stream_ptr()), "vpc_nm_mul")
 
 
+def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, state=None):
+    check(lib().vpc_nm_prep(ptr(x), ptr(mask), ptr(mask_p_out), ptr(xin), B, d, float(keep_prob), int(seed), int(offset),
+                            ptr(state), stream_ptr()), "vpc_nm_prep")
+
+
+def nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, hq, hp, W, b, eps_kl, g_xm_q, g_xl_q, g_xm_p, g_xl_p,
+            ldg, ghq, ghp, gW, gb, xm_imp, scratch, out8, loss_f32, accum, B, B_global, K, d, Ld, alpha):
+    check(lib().vpc_nm_loss(ptr(x), ptr(mask), ptr(mask_p), ptr(xm_q), ptr(xl_q), ldq, ptr(xm_p), ptr(xl_p), ldp,
+                            ptr(hq), ptr(hp), 2 * Ld, ptr(W), ptr(b), ptr(eps_kl), ptr(g_xm_q), ptr(g_xl_q), ldg,
+                            ptr(g_xm_p), ptr(g_xl_p), ldg, ptr(ghq), ptr(ghp), 2 * Ld, ptr(gW), ptr(gb), 0,
+                            ptr(xm_imp), ptr(scratch), scratch.numel() * scratch.element_size(), ptr(out8),
+                            ptr(loss_f32), ptr(accum), B, B_global, K, d, Ld, float(alpha), stream_ptr()),
+          "vpc_nm_loss")
+
+
 def _f32c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
@@ -221,11 +236,9 @@ class NMLossFn(torch.autograd.Function):
         scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
         out8 = torch.empty(8, dtype=torch.float64, device=dev)
         half = lambda G: None if G is None else G[:, d:]
-        check(lib().vpc_nm_loss(ptr(x), ptr(mask), ptr(mask_p), ptr(xm_q), ptr(xl_q), ldq, ptr(xm_p), ptr(xl_p), ldp,
-                                ptr(heads_q), ptr(heads_p), 2 * Ld, ptr(W), ptr(b), ptr(eps_kl), ptr(Gq), ptr(half(Gq)),
-                                2 * d, ptr(Gp), ptr(half(Gp)), 2 * d, ptr(ghq), ptr(ghp), 2 * Ld, ptr(gW), ptr(gb), 0,
-                                ptr(xm_imp), ptr(scratch), scratch.numel() * 8, ptr(out8), B, cfg.get("B_global", B), K,
-                                d, Ld, float(cfg["alpha"]), stream_ptr()), "vpc_nm_loss")
+        nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, heads_q, heads_p, W, b, eps_kl, Gq, half(Gq), Gp,
+                half(Gp), 2 * d, ghq, ghp, gW, gb, xm_imp, scratch, out8, None, None, B, cfg.get("B_global", B), K, d,
+                Ld, cfg["alpha"])
         ctx.reg, ctx.need_grad, ctx.dims = reg, need_grad, (B, K, d, Ld)
         ctx.wshape = W.shape
         if need_grad:
@@ -477,3 +490,145 @@ class notMIWAE_myversion(_NMBase):
         if eps_kl is None:
             eps_kl = torch.randn(B, self.num_samples, self.latent_dim, device=x.device)
         return self._loss(x, mask, None, (x_recon, x_logvar, mean, logvar), None, 0.0, _f32c(eps_kl), llh_eval)
+
+
+# ------------------------------------------------------------------------------------------------ fused step
+class NMTrainer:
+    """The whole training step of the MNAR path (train.py:28-117 for 'reg_notMIWAE*' / 'vanilla_notMIWAE*') as a
+    fixed sequence of HIP launches, no host synchronisation: float mask_p draw + stacked encoder input, Philox
+    normals, encoder / decoder GEMM chains with the q and p passes STACKED along the batch (one GEMM per layer for
+    both passes), the fused loss kernel, the backward GEMM chain writing straight into one flat gradient buffer,
+    one all-reduce of [grads | loss] under data parallelism, flat Adam."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+        if not isinstance(model, _NMBase):
+            raise TypeError("NMTrainer supports REG_notMIWAE_v2 and notMIWAE_myversion")
+        self.model, self.reg = model, model.regularised
+        self.lr, self.betas, self.eps_adam = lr, betas, eps
+        self.seed, self.rng_offset, self.step_count = seed, 0, 0
+        self.pg, self.world_size = process_group, world_size
+        flat = model.flatten_parameters()
+        L.require_cuda(flat)
+        self.dev = flat.device
+        n = flat.numel()
+        self.bucket = torch.zeros(n + 1, device=self.dev)  # [grads | loss] -> ONE all-reduce per step
+        self.grad, self.loss = self.bucket[:n], self.bucket[n:]
+        self.exp_avg = torch.zeros(n, device=self.dev)
+        self.exp_avg_sq = torch.zeros(n, device=self.dev)
+        self.accum = torch.zeros(1, device=self.dev)
+        self.out8 = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        d = model.obs_dim
+        self.g = model._segment_views(self.grad[:2 * d], "wb")
+        self.g.update(model._segment_views(self.grad[2 * d:2 * d + model._n_enc], "enc"))
+        self.g.update(model._segment_views(self.grad[2 * d + model._n_enc:], "dec"))
+        off = 0
+        for p in model.trainable():
+            p.grad = self.grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._B = None
+        self.timers = None
+
+    def _ws(self, B):
+        if self._B == B:
+            return
+        m, dev = self.model, self.dev
+        d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
+        P = 2 if self.reg else 1
+        R, M = P * B, P * B * K
+        e = lambda *s: torch.empty(*s, device=dev)
+        self.xin, self.mask_p = e(R, d), e(B, d)
+        self.h1, self.h2, self.heads = e(R, HID), e(R, HID), e(R, 2 * Ld)
+        self.eps = e(2, B, K, Ld)  # reg: eps_q, eps_p; vanilla: eps (sampling), eps_kl (MC KL)
+        self.z, self.g1, self.g2, self.Y = e(M, Ld), e(M, HID), e(M, HID), e(M, 2 * d)
+        self.G, self.gheads, self.dht = e(M, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
+        self.dg2, self.dg1, self.dz = e(M, HID), e(M, HID), e(M, Ld)
+        self.dh2, self.dh1 = e(R, HID), e(R, HID)
+        nbytes = int(lib().vpc_nm_loss_scratch(B, d))
+        self.scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+        self._B = B
+
+    def _t(self, name, fn, *a, **kw):
+        if self.timers is None:
+            return fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        self.timers.setdefault(name, []).append((e0, e1))
+        return r
+
+    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30):
+        """One optimiser step.  mask_p / eps ([2, B, K, L]: (eps_q, eps_p) or (eps, eps_kl)) may be injected for
+        parity tests; otherwise they are drawn on the device."""
+        m = self.model
+        v = m._views()
+        d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
+        xf, mf = _f32c(x.reshape(-1, d)), _f32c(mask.reshape(-1, d))
+        L.require_cuda(xf, mf)
+        B = xf.shape[0]
+        Bg = B * self.world_size
+        self._ws(B)
+        reg = self.reg
+        P = 2 if reg else 1
+        R, M, BK = P * B, P * B * K, B * K
+        t = self._t
+        # ---- inputs
+        if reg and mask_p is not None:
+            mp = _f32c(mask_p.reshape(-1, d))
+            nm_mul(xf, mf, self.xin[:B])
+            nm_mul(xf, mp, self.xin[B:])
+        else:
+            mp = self.mask_p if reg else None
+            t("prep", nm_prep, xf, mf, mp, self.xin, B, d, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset)
+        if eps is None:
+            from .ops import fill_normal
+            t("normal", fill_normal, self.eps, self.seed, self.rng_offset + (1 << 40))
+            self.rng_offset += (2 * B * K * Ld + 3) // 4 + (B * d + 3) // 4
+        else:
+            self.eps.copy_(eps)
+        # ---- forward
+        t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU)
+        t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU)
+        t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE)
+        t("sample", nm_sample, self.heads, self.eps if reg else self.eps[0], self.z, R, K, Ld)
+        t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU)
+        t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU)
+        t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d)
+        # ---- loss + output-side gradients
+        Y, G = self.Y, self.G
+        t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
+          self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
+          G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
+          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss, self.accum, B, Bg, K, d, Ld, alpha)
+        # ---- backward
+        g = self.g
+        gate = dict(y_gate=Y, gate=ACT_SIGMOID_HARDTANH, gate_split=d)
+        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID, **gate)
+        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, **gate)
+        t("dec_wgrad2", linear_wgrad, self.dg2, self.g1, g["Wd2"], g["bd2"], M, HID, HID)
+        t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU)
+        t("dec_wgrad1", linear_wgrad, self.dg1, self.z, g["Wd1"], g["bd1"], M, HID, Ld)
+        t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld)
+        t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
+          K, Ld)
+        t("enc_bwd", linear_wgrad, self.dht, self.h2, g["Wh"], g["bh"], R, 2 * Ld, HID)
+        t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU)
+        t("enc_bwd", linear_wgrad, self.dh2, self.h1, g["We2"], g["be2"], R, HID, HID)
+        t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU)
+        t("enc_bwd", linear_wgrad, self.dh1, self.xin, g["We1"], g["be1"], R, HID, d)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        self.step_count += 1
+        from .ops import adam_step
+        t("adam", adam_step, m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+          self.betas[0], self.betas[1], self.eps_adam)
+
+    def loss_value(self) -> float:
+        return float(self.loss.item())
+
+    def epoch_total(self, reset=True) -> float:
+        v = float(self.accum.item())
+        if reset:
+            self.accum.zero_()
+        return v
