@@ -9,6 +9,8 @@ Authoring container only: imports /root/reference (never copied, never shipped) 
                            parameter grads, the llh_eval branch (xm, RE_q.mean())
   nm_van_d{14,40}.npz      notMIWAE_myversion (VAE.py:2691-2847): same, incl. the fresh eps drawn inside loss()
   nm_traj_{reg,van}_d14.npz  5 Adam steps exactly as train.py:87-117 runs them
+  nm_eval_{reg,van}_d14.npz  (--eval) the reference's eval_vae_mnar (evaluate.py:13-69) on a checkpoint in its own
+                           naming scheme: parameters, test rows and the RMSE it wrote
 """
 import os
 import sys
@@ -147,6 +149,58 @@ def gen_traj(kind, d=14, L=10, K=20, B=16, steps=5, seed=4242):
     np.savez_compressed(os.path.join(OUT, f"nm_traj_{kind}_d{d}.npz"), **out)
     print("nm_traj", kind, losses)
 
+
+def gen_eval_mnar(kind, d=14, L=10, N=24, valid_k=4000, M=3, seed=606):
+    """The reference's own eval_vae_mnar (evaluate.py:13-69) on a checkpoint written in its naming scheme: pins
+    the checkpoint interop and the importance-weighted imputation RMSE (an MC estimate: compare within noise)."""
+    import tempfile
+    from src.experiment_main.evaluate import eval_vae_mnar
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    vae_type = "reg_notMIWAE1" if kind == "reg" else "vanilla_notMIWAE1"
+    model = (REG_notMIWAE_v2 if kind == "reg" else notMIWAE_myversion)(d, 500, 10, L, TP, 20, 1)
+    opt = torch.optim.Adam(model.parameters(), lr=0.003)
+    x, mask, _ = make_inputs(N, d, seed + 1)
+    for s in range(60):  # a few steps so that the imputations are not trivial
+        if kind == "reg":
+            mp = mask * (torch.rand(N, d) < 0.5).float()
+            o = model.forward(x, mask, mp)
+            _, tl = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mp, s + 1, alpha=0.5)
+        else:
+            o = model.forward(x, mask)
+            _, tl = model.loss(x, o[2], o[3], o[0], o[1], s + 1, mask)
+        opt.zero_grad(); tl.backward(); opt.step()
+    out = {"param." + k: v for k, v in sd_np(model).items()}
+    fam = "".join(c for c in vae_type if not c.isdigit())
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for sub in ("checkpoints", "rest"):
+                os.makedirs(os.path.join("experiments", "exp", "toy", sub, fam))
+            if kind == "reg":
+                ck = f"experiments/exp/toy/checkpoints/{fam}/checkpoint_{vae_type}_0.5_50_kl_reg_50_missing_rate_full_reg_test.pt"
+            else:
+                ck = f"experiments/exp/toy/checkpoints/{fam}/checkpoint_{vae_type}_50_missing_rate_test.pt"
+            torch.save(model.state_dict(), ck)
+            eval_vae_mnar(x, mask, 50, d, 500, 10, M, L, "toy", TP, "exp", vae_type, 100, valid_k, 1, alpha=0.5,
+                          p_missingness=50, reg_type="kl_reg")
+            files = os.listdir(f"experiments/exp/toy/rest/{fam}")
+            assert len(files) == 1, files
+            rmse = torch.load(os.path.join(f"experiments/exp/toy/rest/{fam}", files[0]))
+            out["result_file"] = np.array(files[0])
+        finally:
+            os.chdir(cwd)
+    out.update(x=x.numpy(), mask=mask.numpy(), rmse=np.float64(rmse.item()), valid_k=np.int64(valid_k), M=np.int64(M),
+               L=np.int64(L), K=np.int64(20))
+    np.savez_compressed(os.path.join(OUT, f"nm_eval_{kind}_d{d}.npz"), **out)
+    print("nm_eval", kind, rmse.item(), files[0])
+
+
+if __name__ == "__main__" and "--eval" in sys.argv:
+    gen_eval_mnar("reg")
+    gen_eval_mnar("van")
+    sys.exit(0)
 
 if __name__ == "__main__":
     gen_reg(14, 10, 20, 16, 31)

@@ -293,3 +293,46 @@ def test_fused_trainer_device_draws(nm, kind):
         assert losses[-1] < losses[0]
         finals.append((losses, model._flat.clone()))
     assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_eval_vae_mnar_checkpoint_interop(nm, kind, tmp_path, monkeypatch):
+    """A checkpoint in the reference's naming scheme loads through model_loader('test') and eval_vae_mnar
+    (evaluate.py:13-69) reproduces the RMSE the reference wrote for it (an MC estimate: 1.5 % tolerance), under the
+    reference's result file name."""
+    import os
+    import vpc_amd
+    g = load_golden(f"nm_eval_{kind}_d14.npz")
+    vae_type = "reg_notMIWAE1" if kind == "reg" else "vanilla_notMIWAE1"
+    monkeypatch.chdir(tmp_path)
+    ck = vpc_amd.checkpoint_path("exp", "toy", vae_type, 50, alpha=0.5, p_missingness=50, reg_type="kl_reg")
+    os.makedirs(os.path.dirname(ck))
+    torch.save({k[6:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("param.")}, ck)
+    x, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"])
+    rmse = vpc_amd.eval_vae_mnar(x, mask, 50, 14, 500, 10, int(g["M"]), int(g["L"]), "toy",
+                                 {"batch_size": 128, "patience": 1}, "exp", vae_type, 100, int(g["valid_k"]), 1,
+                                 alpha=0.5, p_missingness=50, reg_type="kl_reg", max_decoder_rows=40000)
+    assert abs(rmse.item() - float(g["rmse"])) <= 0.015 * float(g["rmse"]), (rmse.item(), float(g["rmse"]))
+    fam = "".join(c for c in vae_type if not c.isdigit())
+    assert os.listdir(os.path.join("experiments", "exp", "toy", "rest", fam)) == [str(g["result_file"])]
+
+
+def test_harness_train_mnar(nm, tmp_path, monkeypatch):
+    """train() (train.py:13-133) for the MNAR families: fused NMTrainer and the API path both lower the loss and
+    write the reference-named checkpoint, which loads back."""
+    import vpc_amd
+    from torch.utils.data import DataLoader, TensorDataset
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    x = torch.rand(96, 14)
+    m = (torch.rand(96, 14) < 0.7).float()
+    loader = DataLoader(TensorDataset(x, m), batch_size=32, shuffle=False)
+    for vae_type, fused in (("reg_notMIWAE1", True), ("vanilla_notMIWAE1", True), ("reg_notMIWAE1", False)):
+        torch.manual_seed(1)
+        model = vpc_amd.train(loader, 50, 14, 500, 10, 1, 10, "toy", {"batch_size": 32, "patience": 1}, "exp",
+                              vae_type, 5, 1, max_epochs=3, alpha=0.5, p_missingness=50, reg_type="kl_reg",
+                              fused=fused, verbose=False)
+        again = vpc_amd.model_loader("test", 14, 500, 10, 10, 50, "toy", {"batch_size": 32, "patience": 1}, 3, 5, 1,
+                                     "exp", "kl_reg", vae_type, alpha=0.5, p_missingness=50)
+        for (k, a), (_, b) in zip(model.state_dict().items(), again.state_dict().items()):
+            assert torch.equal(a.cpu(), b.cpu()), k

@@ -8,12 +8,16 @@ from . import _lib
 from ._lib import VpcError, LIB_PATH
 from .models import Reg_VAE, vanilla_VAE, Reg_VAE_mask, vanilla_VAE_mask, MAX_EPOCH
 from .fused import FusedTrainer
-from .harness import create_missing_uci, model_loader, checkpoint_path, train, eval_vae, result_paths
+from .notmiwae import REG_notMIWAE_v2, notMIWAE_myversion, NMTrainer
+from .harness import (create_missing_uci, model_loader, checkpoint_path, train, eval_vae, result_paths, eval_vae_mnar,
+                      mnar_result_path)
+from . import notmiwae
 from . import ops
 from . import dist as dp
 from . import active
 from .active import reward_matrix, R_lindley_chain, chaini_I, chaini_II
 
-__all__ = ["Reg_VAE", "vanilla_VAE", "Reg_VAE_mask", "vanilla_VAE_mask", "FusedTrainer", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
+__all__ = ["Reg_VAE", "vanilla_VAE", "Reg_VAE_mask", "vanilla_VAE_mask", "FusedTrainer", "REG_notMIWAE_v2",
+           "notMIWAE_myversion", "NMTrainer", "notmiwae", "eval_vae_mnar", "mnar_result_path", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
            "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH", "active", "reward_matrix", "R_lindley_chain", "chaini_I",
            "chaini_II"]

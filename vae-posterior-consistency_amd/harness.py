@@ -5,9 +5,11 @@
   checkpoint_path      src/experiment_main/train.py:120-131
   train                src/experiment_main/train.py:13-133   epoch / batch loop, Adam(lr=1e-3), save at end
   eval_vae             src/experiment_main/evaluate.py:136-297  M MC passes: imputation RMSE on ~mask, ELBO, NLL
+  eval_vae_mnar        src/experiment_main/evaluate.py:13-69    importance-weighted imputation RMSE (MNAR path)
 
-Only the classes named by the hot path are built (Reg_VAE, vanilla_VAE); other vae_type families raise
-NotImplementedError (out of scope).
+Only the classes named by the hot path are built (Reg_VAE, vanilla_VAE and their *_mask variants,
+REG_notMIWAE_v2, notMIWAE_myversion); other vae_type families raise NotImplementedError (out of scope,
+SURVEY.md section 8).
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ from . import _lib as L
 from . import ops
 from .fused import FusedTrainer
 from .models import Reg_VAE, Reg_VAE_mask, vanilla_VAE, vanilla_VAE_mask
+from .notmiwae import NMTrainer, REG_notMIWAE_v2, notMIWAE_myversion
 
 _seed_counter = [0]
 
@@ -52,10 +55,15 @@ def model_loader(stage, obs_dim, hid_dim, K, latent_dim, missing_rate, data_type
                  num_samples, num_estimates, experiment_type, reg_type, vae_type="vae", alpha=1.0, p_missingness=30,
                  beta=0.5, beta_annealing=True, alpha_annealing=True, not_miwae_type="changed"):
     """Same positional signature and substring dispatch as loaders.py:13-246 for the in-scope families."""
-    if "flow" in vae_type or "notMIWAE" in vae_type or "EDDI" in vae_type or "MIWAE" in vae_type:
-        raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* are on the accelerated path")
+    if "flow" in vae_type or "EDDI" in vae_type or ("MIWAE" in vae_type and "notMIWAE" not in vae_type):
+        raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* / *_notMIWAE* are on the "
+                                  "accelerated path")
     augm = "mask_augm" in vae_type  # loaders.py:47, 143
-    if "reg_vae" in vae_type:
+    if "reg_notMIWAE" in vae_type:  # loaders.py:89-103
+        model = REG_notMIWAE_v2(obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates)
+    elif "vanilla_notMIWAE" in vae_type:  # loaders.py:219-233
+        model = notMIWAE_myversion(obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates)
+    elif "reg_vae" in vae_type:
         model = (Reg_VAE_mask if augm else Reg_VAE)(obs_dim, hid_dim, K, latent_dim, training_parameters,
                                                     experiment_type, reg_type, num_samples, num_estimates)
     elif "vanilla_vae" in vae_type:
@@ -76,7 +84,7 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
           experiment_type, vae_type, train_k, num_estimates, max_epochs=1000, device=torch.device("cuda"), alpha=1.0,
           stage="train", p_missingness=30, reg_type="ml_reg", beta=1.0, beta_annealing=False, alpha_annealing=True,
           not_miwae_type="changed", fused=True, seed=0, save=True, verbose=True):
-    """train.py:13-133 for reg_vae* / vanilla_vae*.  With fused=True every batch is one FusedTrainer.step (no
+    """train.py:13-133 for reg_vae* / vanilla_vae* / reg_notMIWAE* / vanilla_notMIWAE*.  With fused=True every batch is one FusedTrainer.step (no
     per-step host sync: the epoch total is read once per epoch, as the reference only prints it per epoch);
     with fused=False it is the reference's own sequence model.forward -> model.loss -> backward -> optim.Adam
     on the API path.  Returns the trained model."""
@@ -84,10 +92,11 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
                          max_epochs, train_k, num_estimates, experiment_type, reg_type, vae_type, alpha=alpha,
                          p_missingness=p_missingness)
     model.to(device)
-    loader, _ = data_loader_train  # train.py:22-23
+    nm = "notMIWAE" in vae_type
+    loader = data_loader_train if nm else data_loader_train[0]  # train.py:22-25
     is_reg = "reg" in vae_type
     if fused:
-        trainer = FusedTrainer(model, lr=0.001, seed=seed)
+        trainer = (NMTrainer if nm else FusedTrainer)(model, lr=0.001, seed=seed)
     else:
         model.flatten_parameters()
         optimizer = torch.optim.Adam(model.parameters(), lr=0.001)  # train.py:21
@@ -96,12 +105,17 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
         for data_sample, mask in loader:
             data_sample = data_sample.to(device)
             mask = mask.to(device)
+            if fused and nm:
+                trainer.step(data_sample, mask, alpha=alpha, p_missingness=p_missingness)
+                continue
             if fused:
                 trainer.step(data_sample, mask, epoch=i + 1, alpha=alpha, beta=beta, beta_annealing=beta_annealing,
                              p_missingness=p_missingness)
                 continue
             if is_reg:  # train.py:53-56, 87-94
                 mask_p = create_missing_uci(data_sample.shape, p_missingness, device=device) * mask
+                if nm:
+                    mask_p = mask_p.float()
                 o = model.forward(data_sample, mask, mask_p, stage=stage)
                 _, train_loss = model.loss(data_sample, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mask_p,
                                            i + 1, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
@@ -203,3 +217,59 @@ def eval_vae(list_loaders, missing_rate, obs_dim, hid_dim, K, M, latent_dim, dat
                     os.makedirs(os.path.dirname(pth), exist_ok=True)
                     torch.save(out[loader_stage][k], pth)
     return out
+
+
+def mnar_result_path(experiment_type, data_type, vae_type, alpha=0.5, p_missingness=30, reg_type="ml_reg",
+                     not_miwae_type="changed"):
+    """File eval_vae_mnar writes (evaluate.py:56-69)."""
+    rest = os.path.join("experiments", experiment_type, data_type, "rest", "".join(c for c in vae_type if not c.isdigit()))
+    if "vanilla" in vae_type:
+        return os.path.join(rest, f"{vae_type}_rmse_{not_miwae_type}_large_batch_test.pt")
+    return os.path.join(rest, f"{vae_type}_rmse_{alpha}_{p_missingness}_{reg_type}_full_reg_large_batch_v2_test.pt")
+
+
+def eval_vae_mnar(data_test, mask_test, missing_rate, obs_dim, hid_dim, K, M, latent_dim, data_type,
+                  training_parameters, experiment_type, vae_type, max_epochs, valid_k, num_estimates,
+                  device=torch.device("cuda"), alpha=0.5, stage="evaluate", p_missingness=30, reg_type="ml_reg",
+                  beta=1.0, beta_annealing=False, alpha_annealing=True, not_miwae_type="changed", model=None,
+                  save=True, max_decoder_rows=1 << 20):
+    """evaluate.py:13-69: M repetitions of the self-normalised importance-weighted imputation with valid_k samples
+    per row, RMSE on the missing entries.  The reference walks the test set ONE ROW per forward (and redraws a
+    full-size mask for each row); here rows are processed in chunks of max_decoder_rows / valid_k per launch
+    sequence, one mask_p draw per repetition - the same estimator, row-independent, so the result has the same
+    distribution.  Returns the RMSE (0-dim CPU tensor) and, with save=True, writes the reference's result file."""
+    with torch.no_grad():
+        if model is None:
+            model = model_loader("test", obs_dim, hid_dim, K, latent_dim, missing_rate, data_type, training_parameters,
+                                 max_epochs, valid_k, num_estimates, experiment_type, reg_type, vae_type, alpha=alpha,
+                                 p_missingness=p_missingness, not_miwae_type=not_miwae_type)
+        model.to(device)
+        is_reg = "reg_notMIWAE" in vae_type
+        data_test = data_test.to(device).float().reshape(-1, obs_dim)
+        mask_test = mask_test.to(device).float().reshape(-1, obs_dim)
+        N = data_test.shape[0]
+        rows = max(1, max_decoder_rows // max(1, model.num_samples))
+        temp_recon = []
+        for _ in range(M):
+            XM = torch.zeros_like(data_test)
+            mask_p = create_missing_uci(data_test.shape, p_missingness, device=device).float() * mask_test
+            for lo in range(0, N, rows):
+                x, m, mp = data_test[lo:lo + rows], mask_test[lo:lo + rows], mask_p[lo:lo + rows]
+                if is_reg:
+                    o = model.forward(x, m, mp, stage=stage)
+                    xm, _, _ = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], m, mp, max_epochs,
+                                          llh_eval=True, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
+                                          alpha_annealing=alpha_annealing, stage=stage)
+                else:
+                    o = model.forward(x, m)
+                    xm, _, _ = model.loss(x, o[2], o[3], o[0], o[1], max_epochs, m, llh_eval=True,
+                                          beta_annealing=beta_annealing, beta=beta, stage=stage)
+                XM[lo:lo + rows] = xm
+            inv = 1 - mask_test
+            temp_recon.append(torch.sqrt(torch.sum(torch.square(XM * inv - data_test * inv)) / torch.sum(inv)))
+        recon = torch.stack(temp_recon).mean().cpu()
+        if save:
+            pth = mnar_result_path(experiment_type, data_type, vae_type, alpha, p_missingness, reg_type, not_miwae_type)
+            os.makedirs(os.path.dirname(pth), exist_ok=True)
+            torch.save(recon, pth)
+    return recon
