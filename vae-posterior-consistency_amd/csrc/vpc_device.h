@@ -253,6 +253,22 @@ __device__ __forceinline__ void launder(int& c, int& q) {
     __builtin_amdgcn_sched_barrier(0);  // phases are scheduled separately: bounds live ranges at 256 VGPRs
 }
 
+// 64-lane sum without LDS traffic: four DPP adds give every lane its 16-lane row sum, four v_readlane + adds the
+// total (uniform).  ~12 VALU instructions against 6 dependent ds_bpermute round trips for the shuffle version.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

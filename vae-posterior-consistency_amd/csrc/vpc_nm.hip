@@ -27,15 +27,19 @@ struct NMLossArgs {
     float* g_xm_q; float* g_xl_q; long ldg_q;                // gradients (nullptr: forward only)
     float* g_xm_p; float* g_xl_p; long ldg_p;
     float* g_hq; float* g_hp; long ldgh;                     // [B][2L]
-    float* gwb_part;                                         // [n_waves][2][d]
+    float* gwb_part;                                         // [n_blocks][2][d]
     float* xm_imp;                                           // [B][d] self-normalised imputation (llh_eval), or nullptr
-    double* rowstat;                                         // [B][NM_STATS]
+    double* stat_part;                                       // [n_blocks][NM_STATS]
     int B, K, d, L;
     float oq, op, oe, cr;                                    // gradient weights: (1-a)/B, a/B, a/(BK), a/(BL)
     float kq, kp;                                            // weights of the analytic KL gradients: (1-a)/B, a/B
 };
-constexpr int NM_STATS = 5;  // lse_q, lse_p, sum_k RE_e, sum_l kl_el, sum_k RE_q
+constexpr int NM_STATS = 5;  // sums over rows of: lse_q, lse_p, sum_k RE_e, sum_l kl_el, sum_k RE_q
 
+// hardware exp / log / rcp (v_exp_f32, v_log_f32, v_rcp_f32: <= 1-2 ulp) for the per-element work of the loss kernel;
+// the once-per-workgroup W transforms and the scalar log-sum-exp keep the IEEE routines
+__device__ __forceinline__ float fexp(float v) { return __expf(v); }
+__device__ __forceinline__ float frcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 __device__ __forceinline__ float sigmoid_f(float v) {
     const float e = expf(-fabsf(v));
@@ -44,17 +48,19 @@ __device__ __forceinline__ float sigmoid_f(float v) {
 struct Lse {  // online log-sum-exp
     float mx = -INFINITY, s = 0.f;
     __device__ __forceinline__ void add(float v) {
-        if (v > mx) { s = s * expf(mx - v) + 1.f; mx = v; } else s += expf(v - mx);
+        if (v > mx) { s = s * fexp(mx - v) + 1.f; mx = v; } else s += fexp(v - mx);
     }
     __device__ __forceinline__ float value() const { return mx + logf(s); }
 };
 
 template <int T, bool REG>
 __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
-    extern __shared__ float lds[];
-    float* spW = lds;            // softplus(W)
-    float* sgW = lds + a.d;      // sigmoid(W) = d softplus
-    float* bb = lds + 2 * a.d;
+    extern __shared__ __align__(8) float lds[];
+    double* stat_sh = reinterpret_cast<double*>(lds);   // [4 waves][NM_STATS]
+    float* spW = lds + 2 * 4 * NM_STATS;                 // softplus(W)
+    float* sgW = spW + a.d;                              // sigmoid(W) = d softplus
+    float* bb = sgW + a.d;
+    float* gsh = bb + a.d;                               // [4 waves][2 d] dW | db
     for (int j = threadIdx.x; j < a.d; j += blockDim.x) {
         const float w = a.W[j];
         spW[j] = softplus_f(w); sgW[j] = sigmoid_f(w); bb[j] = a.b[j];
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
         sp[t] = j < d ? spW[j] : 0.f; sg[t] = j < d ? sgW[j] : 0.f; bj[t] = j < d ? bb[j] : 0.f;
     }
     const float cd = NM_HALF_LOG_2PI * (float)d;
+    double st[NM_STATS] = {0.0, 0.0, 0.0, 0.0, 0.0};
 
     for (int b = gwave; b < a.B; b += nwaves) {
         float x[T], m[T], mp[T];
@@ -93,9 +100,9 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             if (lok) { mu_p = a.hp[(long)b * a.ldh + lane]; lv_p = a.hp[(long)b * a.ldh + L + lane]; }
             const float eq = expf(lv_q), ep = expf(lv_p), ivp = expf(-lv_p), ratio = expf(lv_q - lv_p);
             const float dm = mu_q - mu_p;
-            KLq = wave_sum(lok ? 0.5f * (eq + mu_q * mu_q - 1.f - lv_q) : 0.f);
-            KLp = wave_sum(lok ? 0.5f * (ep + mu_p * mu_p - 1.f - lv_p) : 0.f);
-            klel = wave_sum(lok ? 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p)) : 0.f);
+            KLq = wave_sum_dpp(lok ? 0.5f * (eq + mu_q * mu_q - 1.f - lv_q) : 0.f);
+            KLp = wave_sum_dpp(lok ? 0.5f * (ep + mu_p * mu_p - 1.f - lv_p) : 0.f);
+            klel = wave_sum_dpp(lok ? 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p)) : 0.f);
             if (grad && lok) {
                 float* gq = a.g_hq + (long)b * a.ldgh;
                 float* gp = a.g_hp + (long)b * a.ldgh;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 const bool ok = j < d;
                 const float xm = ok ? a.xm_q[row * a.ld_q + j] : 0.f;
                 const float xl = ok ? a.xl_q[row * a.ld_q + j] : 0.f;
-                const float iv = expf(-xl), r = x[t] - xm;
+                const float iv = fexp(-xl), r = x[t] - xm;
                 riv[t] = r * iv;                       // (x - xm) / var
                 hq2[t] = 0.5f - 0.5f * r * riv[t];     // d/dxl of the element NLL
                 const float el = 0.5f * xl + 0.5f * r * riv[t];
@@ -128,12 +135,13 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 if (REG) s_ree += m[t] * (1.f - mp[t]) * el;
                 mix[t] = xm * (1.f - m[t]) + x[t] * m[t];
                 const float lg = -sp[t] * (mix[t] - bj[t]);
-                s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + log1pf(expf(-fabsf(lg))) : 0.f;
-                dn[t] = sigmoid_f(lg) - m[t];
+                const float el2 = fexp(-fabsf(lg)), rc = frcp(1.f + el2);
+                s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + __logf(1.f + el2) : 0.f;
+                dn[t] = (lg >= 0.f ? rc : el2 * rc) - m[t];
                 if (REG) {
                     const float xmp = ok ? a.xm_p[row * a.ld_p + j] : 0.f;
                     const float xlp = ok ? a.xl_p[row * a.ld_p + j] : 0.f;
-                    const float ivp = expf(-xlp), rp = x[t] - xmp;
+                    const float ivp = fexp(-xlp), rp = x[t] - xmp;
                     rivp[t] = rp * ivp;
                     hp2[t] = 0.5f - 0.5f * rp * rivp[t];
                     s_rep += mp[t] * (0.5f * xlp + 0.5f * rp * rivp[t]);
@@ -144,15 +152,15 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 const float e = lok ? a.eps_kl[row * L + lane] : 0.f;
                 const float z = mu_q + e * sd_q;
                 z_out = z; e_out = e;
-                KL = wave_sum(lok ? -0.5f * e * e - 0.5f * lv_q + 0.5f * z * z : 0.f);
+                KL = wave_sum_dpp(lok ? -0.5f * e * e - 0.5f * lv_q + 0.5f * z * z : 0.f);
             }
-            const float RE_q = wave_sum(s_req) + cd;
-            const float nlp = wave_sum(s_nlp);
+            const float RE_q = wave_sum_dpp(s_req) + cd;
+            const float nlp = wave_sum_dpp(s_nlp);
             lwq = RE_q + KL + nlp;
             re_q_out = RE_q;
             if (REG) {
-                re_e_out = wave_sum(s_ree) + cd;
-                lwp = wave_sum(s_rep) + cd + KLp;
+                re_e_out = wave_sum_dpp(s_ree) + cd;
+                lwp = wave_sum_dpp(s_rep) + cd + KLp;
             }
         };
 
@@ -168,10 +176,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             sum_req += req;
         }
         const float lse_q = lq.value(), lse_p = REG ? lp.value() : 0.f, lse_n = ln.value();
-        if (lane == 0) {
-            double* rs = a.rowstat + (long)b * NM_STATS;
-            rs[0] = lse_q; rs[1] = lse_p; rs[2] = sum_ree; rs[3] = klel; rs[4] = sum_req;
-        }
+        st[0] += lse_q; st[1] += lse_p; st[2] += sum_ree; st[3] += klel; st[4] += sum_req;
         if (!grad && !a.xm_imp) continue;
 
         // ---- pass 2: softmax weights x element derivatives
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             terms(k, lwq, lwp, req, ree, riv, hq2, dn, mix, rivp, hp2, z, e);
             const long row = (long)b * K + k;
             if (a.xm_imp) {
-                const float wi = expf(-lwq - lse_n);
+                const float wi = fexp(-lwq - lse_n);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const int j = lane + 64 * t;
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 }
             }
             if (!grad) continue;
-            const float wq = a.oq * expf(lwq - lse_q);
-            const float wp = REG ? a.op * expf(lwp - lse_p) : 0.f;
+            const float wq = a.oq * fexp(lwq - lse_q);
+            const float wp = REG ? a.op * fexp(lwp - lse_p) : 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int j = lane + 64 * t;
@@ -221,18 +226,30 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             a.g_hq[(long)b * a.ldgh + L + lane] = dlv;
         }
     }
+    // ---- workgroup partials, combined in wave order (fixed => deterministic)
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int i = 0; i < NM_STATS; ++i) stat_sh[wave * NM_STATS + i] = st[i];
     if (grad) {
-        float* P = a.gwb_part + (long)gwave * 2 * d;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int j = lane + 64 * t;
-            if (j < d) { P[j] = gW[t]; P[d + j] = gB[t]; }
+            if (j < d) { gsh[wave * 2 * d + j] = gW[t]; gsh[wave * 2 * d + d + j] = gB[t]; }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < NM_STATS)
+        a.stat_part[(long)blockIdx.x * NM_STATS + threadIdx.x] =
+            (stat_sh[threadIdx.x] + stat_sh[NM_STATS + threadIdx.x]) +
+            (stat_sh[2 * NM_STATS + threadIdx.x] + stat_sh[3 * NM_STATS + threadIdx.x]);
+    if (grad)
+        for (int j = threadIdx.x; j < 2 * d; j += blockDim.x)
+            a.gwb_part[(long)blockIdx.x * 2 * d + j] =
+                (gsh[j] + gsh[2 * d + j]) + (gsh[4 * d + j] + gsh[6 * d + j]);
 }
 
 struct NMFinArgs {
-    const double* rowstat; const float* gwb_part; int n_waves;
+    const double* stat_part; const float* gwb_part; int n_blocks;
     int B, K, d, L; double alpha; int reg;
     double* out;            // [8]: loss, loss_q, loss_p, KL_reg, NLL_E, RE_q mean, sum lse_q, sum lse_p
     float* gW; float* gb;   // [d] each (nullptr: skip)
@@ -241,11 +258,33 @@ struct NMFinArgs {
     int accumulate;
     double inv_B;           // 1 / (rows the means run over): B, or the global batch under data parallelism
 };
+// block 0: the loss terms; block c >= 1: columns [64 (c-1), 64 c) of the dW | db partials, 4 row groups per column
 __global__ __launch_bounds__(256) void nm_finalize_kernel(NMFinArgs a) {
     __shared__ double red[256][NM_STATS];
+    if (blockIdx.x > 0) {
+        float (*gs)[64] = reinterpret_cast<float (*)[64]>(&red[0][0]);
+        const int col = 64 * (blockIdx.x - 1) + (threadIdx.x & 63), grp = threadIdx.x >> 6, C = 2 * a.d;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (col < C) {
+            int w = grp;
+            for (; w + 12 < a.n_blocks; w += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += a.gwb_part[(long)(w + 4 * u) * C + col];
+            }
+            for (; w < a.n_blocks; w += 4) acc[0] += a.gwb_part[(long)w * C + col];
+        }
+        gs[grp][threadIdx.x & 63] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (threadIdx.x < 64 && col < C) {
+            const float v = (gs[0][threadIdx.x] + gs[1][threadIdx.x]) + (gs[2][threadIdx.x] + gs[3][threadIdx.x]);
+            float* dst = col < a.d ? a.gW + col : a.gb + (col - a.d);
+            *dst = a.accumulate ? *dst + v : v;
+        }
+        return;
+    }
     double s[NM_STATS] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < a.B; b += 256)
-        for (int i = 0; i < NM_STATS; ++i) s[i] += a.rowstat[(long)b * NM_STATS + i];
+    for (int b = threadIdx.x; b < a.n_blocks; b += 256)
+        for (int i = 0; i < NM_STATS; ++i) s[i] += a.stat_part[(long)b * NM_STATS + i];
     for (int i = 0; i < NM_STATS; ++i) red[threadIdx.x][i] = s[i];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -265,14 +304,6 @@ __global__ __launch_bounds__(256) void nm_finalize_kernel(NMFinArgs a) {
         a.out[6] = red[0][0]; a.out[7] = red[0][1];
         if (a.loss_f32) a.loss_f32[0] = (float)a.out[0];
         if (a.accum) a.accum[0] += (float)a.out[0];
-    }
-    if (a.gW) {
-        for (int j = threadIdx.x; j < 2 * a.d; j += 256) {
-            float acc = 0.f;
-            for (int w = 0; w < a.n_waves; ++w) acc += a.gwb_part[(long)w * 2 * a.d + j];
-            float* dst = j < a.d ? a.gW + j : a.gb + (j - a.d);
-            *dst = a.accumulate ? *dst + acc : acc;
-        }
     }
 }
 
@@ -313,7 +344,7 @@ __global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restri
 
 template <int T>
 static int launch_loss(const NMLossArgs& a, int reg, int n_blocks, hipStream_t st) {
-    const size_t lds = 3 * (size_t)a.d * sizeof(float);
+    const size_t lds = (2 * 4 * NM_STATS + 3 * (size_t)a.d + 4 * 2 * (size_t)a.d) * sizeof(float);
     if (reg) hipLaunchKernelGGL((nm_loss_kernel<T, true>), dim3(n_blocks), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((nm_loss_kernel<T, false>), dim3(n_blocks), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
@@ -327,15 +358,15 @@ extern "C" {
 
 int vpc_nm_loss_blocks(long B) {
     long blocks = (B + 3) / 4;
-    const long cap = 8L * num_cus();
+    const long cap = 4L * num_cus();  // one resident round at 4 waves / SIMD; the rest is a grid-stride loop
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
-long vpc_nm_loss_scratch(long B, int d) {  // bytes: rowstat doubles + per-wave dW/db partials + 8 output doubles
+long vpc_nm_loss_scratch(long B, int d) {  // bytes: per-workgroup statistics (doubles) + dW | db partials (floats)
     if (B <= 0 || d <= 0) return 0;
-    const long waves = 4L * vpc_nm_loss_blocks(B);
-    return B * NM_STATS * 8 + 64 + waves * 2 * d * 4;
+    const long blocks = vpc_nm_loss_blocks(B);
+    return blocks * NM_STATS * 8 + blocks * 2 * d * 4;
 }
 
 int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const float* xm_q, const float* xl_q, long ld_q,
@@ -360,8 +391,8 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
     a.ld_p = ld_p; a.hq = heads_q; a.hp = heads_p; a.ldh = ldh; a.W = W; a.b = b; a.eps_kl = eps_kl;
     a.g_xm_q = g_xm_q; a.g_xl_q = g_xl_q; a.ldg_q = ldg_q; a.g_xm_p = g_xm_p; a.g_xl_p = g_xl_p; a.ldg_p = ldg_p;
     a.g_hq = g_heads_q; a.g_hp = g_heads_p; a.ldgh = ldgh; a.xm_imp = xm_imp;
-    a.rowstat = reinterpret_cast<double*>(scratch);
-    a.gwb_part = reinterpret_cast<float*>(a.rowstat + B * NM_STATS + 8);
+    a.stat_part = reinterpret_cast<double*>(scratch);
+    a.gwb_part = reinterpret_cast<float*>(a.stat_part + (long)blocks * NM_STATS);
     a.B = (int)B; a.K = K; a.d = d; a.L = L;
     const double al = reg ? alpha : 0.0, Bg = (double)B_global;
     a.oq = (float)((1.0 - al) / Bg); a.op = (float)(al / Bg); a.oe = (float)(al / (Bg * K)); a.cr = (float)(al / (Bg * L));
@@ -371,11 +402,11 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                                                                       : launch_loss<4>(a, reg, blocks, st);
     if (rc != VPC_OK) return rc;
     NMFinArgs f{};
-    f.rowstat = a.rowstat; f.gwb_part = a.gwb_part; f.n_waves = 4 * blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;
+    f.stat_part = a.stat_part; f.gwb_part = a.gwb_part; f.n_blocks = blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;
     f.alpha = al; f.reg = reg; f.out = out8; f.gW = grad ? gW : nullptr; f.gb = gb; f.accumulate = accumulate_wb;
     f.loss_f32 = loss_f32; f.accum = accum;
     f.inv_B = 1.0 / Bg;
-    hipLaunchKernelGGL(nm_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(nm_finalize_kernel, dim3(grad ? 1 + (2 * d + 63) / 64 : 1), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
