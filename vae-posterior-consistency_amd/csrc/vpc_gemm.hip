@@ -9,7 +9,7 @@
 //
 // One kernel template, three modes.  The MFMA is v_mfma_f32_16x16x4_f32 used "transposed" as everywhere in this
 // library: the D tile is [feature 4q+j][row c], so a lane owns 4 consecutive features of one row and the epilogue
-// moves float4s.  A workgroup (4 waves, 2 x 2) computes a 128 x 128 output tile; the contraction runs in chunks of
+// moves float4s.  A workgroup (8 waves, 4 x 2, each 32 x 64 outputs) computes a 128 x 128 output tile; the contraction runs in chunks of
 // 64 through two 32 KB LDS tiles:
 //     row-read tile   [128][64]  (operand indexed [output][contraction]): one ds_read_b128 feeds 4 MFMAs
 //     transposed tile [64][128]  (operand indexed [contraction][output]): 4 ds_read_b32 feed 4 MFMAs
@@ -36,7 +36,7 @@ struct LinArgs {
     int act, split;                // fwd: output activation; dgrad: activation of the PREVIOUS layer (for aux)
     int gate, gate_split;          // activation of THIS layer when Yg is given
     int rows_per_split;            // wgrad
-    int vecA, vecB, vecC;          // 16-byte path usable for the operand / output
+    int vecA, vecB, vecC, vecX;    // 16-byte path usable for the operand / output / aux
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act, bool second) {
@@ -57,17 +57,19 @@ __device__ __forceinline__ float act_grad(float y, int act, bool second) {
     }
 }
 
-constexpr int LIN_THREADS = 256;
-constexpr int LIN_TILE = 8192;  // floats per LDS tile
+constexpr int LIN_THREADS = 512;  // 8 waves: 4 (A-operand index) x 2 (B-operand index); a wave owns 32 x 64 outputs
+constexpr int LIN_TILE = 8192;    // floats per LDS tile
+constexpr int LIN_LD = LIN_TILE / 4 / LIN_THREADS;  // float4 loads per thread and tile (4)
+constexpr int IT = 2, JT = 4;     // 16 x 16 MFMA tiles per wave
 
 // ---- global -> registers: a ROWS x COLS tile (ROWS * COLS = 8192), zero-filled outside [rlim) x [clim)
 template <int COLS>
-__device__ __forceinline__ void gload(f32x4 (&r)[8], const float* __restrict__ base, long ld, int r0, int c0, int rlim,
-                                      int clim, int vec, const float* __restrict__ yg, long ldy, int gate,
+__device__ __forceinline__ void gload(f32x4 (&r)[LIN_LD], const float* __restrict__ base, long ld, int r0, int c0,
+                                      int rlim, int clim, int vec, const float* __restrict__ yg, long ldy, int gate,
                                       int gate_split) {
     constexpr int C4 = COLS / 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < LIN_LD; ++i) {
         const int idx = threadIdx.x + LIN_THREADS * i;
         const int row = r0 + idx / C4, col = c0 + 4 * (idx % C4);
         f32x4 v = zero4();
@@ -82,9 +84,16 @@ __device__ __forceinline__ void gload(f32x4 (&r)[8], const float* __restrict__ b
             }
             if (yg) {
                 const float* py = yg + (long)row * ldy + col;
+                f32x4 y = zero4();
+                if (vec && col + 3 < clim) {
+                    y = *reinterpret_cast<const f32x4*>(py);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < clim) v[e] *= act_grad(py[e], gate, col + e >= gate_split);
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < clim) y[e] = py[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_grad(y[e], gate, col + e >= gate_split);
             }
         }
         r[i] = v;
@@ -92,10 +101,10 @@ __device__ __forceinline__ void gload(f32x4 (&r)[8], const float* __restrict__ b
 }
 // ---- registers -> swizzled LDS tile
 template <int COLS>
-__device__ __forceinline__ void sstore(float* __restrict__ s, const f32x4 (&r)[8]) {
+__device__ __forceinline__ void sstore(float* __restrict__ s, const f32x4 (&r)[LIN_LD]) {
     constexpr int C4 = COLS / 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < LIN_LD; ++i) {
         const int idx = threadIdx.x + LIN_THREADS * i;
         const int row = idx / C4, sl = idx % C4;
         *reinterpret_cast<f32x4*>(s + row * COLS + ((sl ^ (row & 15)) << 2)) = r[i];
@@ -116,7 +125,8 @@ __device__ __forceinline__ f32x4 frag_T(const float* __restrict__ s, int ob, int
     return f;
 }
 
-template <int MODE>
+// RAGGED: some 16-wide tile of the layer is empty (L = 10, 2L = 20, d = 14 ...): skip those MFMAs (wave-uniform).
+template <int MODE, bool RAGGED>
 __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
     extern __shared__ __align__(16) float lds[];
     float* sA = lds;
@@ -138,15 +148,17 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
         k_begin = blockIdx.x * a.rows_per_split;
         k_end = min(a.M, k_begin + a.rows_per_split);
     }
+    const int n_it = RAGGED ? min(IT, max(0, (ilim - i0 - 16 * IT * wr + 15) / 16)) : IT;
+    const int n_jt = RAGGED ? min(JT, max(0, (jlim - j0 - 16 * JT * wc + 15) / 16)) : JT;
 
-    f32x4 acc[4][4];
+    f32x4 acc[IT][JT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+        for (int j = 0; j < JT; ++j) acc[i][j] = zero4();
     float bsum = 0.f;  // wgrad: column sum of dY~ (bias gradient), threads 0..127 of the k-tile-0 workgroups
 
-    f32x4 ra[8], rb[8];
+    f32x4 ra[LIN_LD], rb[LIN_LD];
     auto load_chunk = [&](int k0) {
         if (MODE == LIN_FWD) {
             gload<64>(ra, a.A, a.lda, i0, k0, a.N, k_end, a.vecA, nullptr, 0, 0, 0);
@@ -172,34 +184,53 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
 #pragma unroll 8
             for (int r = 0; r < 64; ++r) bsum += sA[r * 128 + (((cs ^ (r & 15)) << 2) | cl)];
         }
+        const int n_kk = RAGGED ? min(4, (k_end - k0 + 15) / 16) : 4;  // contraction sub-blocks with real data
+        if (RAGGED && (n_it == 0 || n_jt == 0)) continue;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[4], fb[4];
+            if (RAGGED && kk >= n_kk) break;
+            f32x4 fa[IT], fb[JT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = AT ? frag_T(sA, 4 * wr + t, kk, c, q) : frag_row(sA, 4 * wr + t, kk, c, q);
-                fb[t] = BT ? frag_T(sB, 4 * wc + t, kk, c, q) : frag_row(sB, 4 * wc + t, kk, c, q);
+            for (int t = 0; t < IT; ++t)
+                fa[t] = (!RAGGED || t < n_it)
+                            ? (AT ? frag_T(sA, IT * wr + t, kk, c, q) : frag_row(sA, IT * wr + t, kk, c, q)) : zero4();
+#pragma unroll
+            for (int t = 0; t < JT; ++t)
+                fb[t] = (!RAGGED || t < n_jt)
+                            ? (BT ? frag_T(sB, JT * wc + t, kk, c, q) : frag_row(sB, JT * wc + t, kk, c, q)) : zero4();
+            if (!RAGGED) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+#pragma unroll
+                        for (int jt = 0; jt < JT; ++jt) acc[it][jt] = VPC_MFMA(fa[it][j], fb[jt][j], acc[it][jt]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    if (it >= n_it) break;
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if (jt >= n_jt) break;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[it][jt] = VPC_MFMA(fa[it][j], fb[jt][j], acc[it][jt]);
+                    }
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) acc[it][jt] = VPC_MFMA(fa[it][j], fb[jt][j], acc[it][jt]);
         }
     }
 
-    // ---- epilogue.  acc[it][jt][e] = D[i0 + 64 wr + 16 it + 4 q + e][j0 + 64 wc + 16 jt + c]
+    // ---- epilogue.  acc[it][jt][e] = D[i0 + 32 wr + 16 it + 4 q + e][j0 + 64 wc + 16 jt + c]
     if (MODE == LIN_WGRAD) {
         float* P = a.C + (long)blockIdx.x * a.N * a.ldc;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < IT; ++it)
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int col = j0 + 64 * wc + 16 * jt + c;
+            for (int jt = 0; jt < JT; ++jt) {
+                const int col = j0 + 16 * JT * wc + 16 * jt + c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int row = i0 + 64 * wr + 16 * it + 4 * q + e;
+                    const int row = i0 + 16 * IT * wr + 16 * it + 4 * q + e;
                     if (row < ilim && col < jlim) P[(long)row * a.ldc + col] = acc[it][jt][e];
                 }
             }
@@ -208,8 +239,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
         return;
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int f = i0 + 64 * wr + 16 * it + 4 * q;  // first of 4 consecutive output features
+    for (int it = 0; it < IT; ++it) {
+        const int f = i0 + 16 * IT * wr + 16 * it + 4 * q;  // first of 4 consecutive output features
         if (f >= ilim) continue;
         f32x4 bv = zero4();
         if (MODE == LIN_FWD && a.bias) {
@@ -218,8 +249,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
                 if (f + e < ilim) bv[e] = a.bias[f + e];
         }
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int row = j0 + 64 * wc + 16 * jt + c;
+        for (int jt = 0; jt < JT; ++jt) {
+            const int row = j0 + 16 * JT * wc + 16 * jt + c;
             if (row >= jlim) continue;
             f32x4 v = acc[it][jt];
             if (MODE == LIN_FWD) {
@@ -227,9 +258,16 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e] + bv[e], a.act, f + e >= a.split);
             } else if (a.aux) {
                 const float* px = a.aux + (long)row * a.ldaux + f;
+                f32x4 xo = zero4();
+                if (a.vecX && f + 3 < ilim) {
+                    xo = *reinterpret_cast<const f32x4*>(px);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (f + e < ilim) v[e] *= act_grad(px[e], a.act, f + e >= a.split);
+                    for (int e = 0; e < 4; ++e)
+                        if (f + e < ilim) xo[e] = px[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_grad(xo[e], a.act, f + e >= a.split);
             }
             float* pc = a.C + (long)row * a.ldc + f;
             if (a.vecC && f + 3 < ilim) {
@@ -265,8 +303,15 @@ static bool vec_ok(const void* p, long ld) { return aligned16(p) && (ld % 4) == 
 template <int MODE>
 static int launch(const LinArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t LDS = 2 * LIN_TILE * sizeof(float);
-    if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE>), LDS)) return VPC_ERR_HIP;
-    hipLaunchKernelGGL(linear_kernel<MODE>, grid, dim3(LIN_THREADS), LDS, st, a);
+    // feature dimensions that leave whole 16-wide tiles / contraction sub-blocks empty take the tile-skipping build
+    const bool ragged = (a.N % 64) != 0 || (a.K % 64) != 0;
+    if (ragged) {
+        if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, true>), LDS)) return VPC_ERR_HIP;
+        hipLaunchKernelGGL((linear_kernel<MODE, true>), grid, dim3(LIN_THREADS), LDS, st, a);
+    } else {
+        if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, false>), LDS)) return VPC_ERR_HIP;
+        hipLaunchKernelGGL((linear_kernel<MODE, false>), grid, dim3(LIN_THREADS), LDS, st, a);
+    }
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -297,7 +342,8 @@ int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     a.gate_split = gate == ACT_SIGMOID_HARDTANH ? gate_split : N;
     a.C = dx; a.ldc = lddx; a.aux = x_out; a.ldaux = ldx; a.act = act_prev; a.split = K;
     a.M = (int)M; a.N = N; a.K = K;
-    a.vecA = vec_ok(w, K); a.vecB = vec_ok(dy, lddy); a.vecC = vec_ok(dx, lddx);
+    a.vecA = vec_ok(w, K); a.vecB = vec_ok(dy, lddy) && (!y_gate || vec_ok(y_gate, ldyg)); a.vecC = vec_ok(dx, lddx);
+    a.vecX = x_out && vec_ok(x_out, ldx);
     return launch<LIN_DGRAD>(a, dim3((unsigned)((M + 127) / 128), (unsigned)((K + 127) / 128)), (hipStream_t)stream);
 }
 
@@ -327,7 +373,7 @@ int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     a.gate_split = gate == ACT_SIGMOID_HARDTANH ? gate_split : N;
     a.B = x; a.ldb = ldx; a.C = scratch; a.ldc = K; a.bias_part = scratch + S * (long)N * K;
     a.M = (int)M; a.N = N; a.K = K; a.rows_per_split = (int)rows_per_split;
-    a.vecA = vec_ok(dy, lddy); a.vecB = vec_ok(x, ldx);
+    a.vecA = vec_ok(dy, lddy) && (!y_gate || vec_ok(y_gate, ldyg)); a.vecB = vec_ok(x, ldx);
     hipStream_t st = (hipStream_t)stream;
     int rc = launch<LIN_WGRAD>(a, dim3((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128)), st);
     if (rc != VPC_OK) return rc;
