@@ -212,7 +212,9 @@ int vpc_nm_mul(const float* x, const float* mask, float* out, long n, void* stre
  * Masks are float 0/1.  out8 (device doubles) = loss, loss_q, loss_p, KL_reg, NLL_E, mean RE_q, sum lse_q,
  * sum lse_p; means run over B_global rows (data parallel: sum out8[0] over ranks).  xm_imp != NULL also
  * writes the self-normalised imputation sum_k softmax(-l_w)_k x_mean[b][k] (llh_eval branch :2458-2461).
- * loss_f32 / accum (optional, device): loss as a float, and accum[0] += loss (train.py:117 without a host sync). */
+ * loss_f32 / accum (optional, device): loss as a float, and accum[0] += loss (train.py:117 without a host sync).
+ * state (optional, two int64 on the device): state[0] += 1 (optimiser step count, read by vpc_adam_step's step_dev)
+ * and state[1] += rng_inc (Philox counter offset read by vpc_nm_prep) - the per-step counters of a replayed graph. */
 int vpc_nm_loss_blocks(long B);
 long vpc_nm_loss_scratch(long B, int d);
 int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const float* xm_q, const float* xl_q, long ld_q,
@@ -220,15 +222,17 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                 const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
                 float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
                 float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8,
-                float* loss_f32, float* accum, long B, long B_global, int K, int d, int L, double alpha,
-                void* stream);
+                float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global, int K, int d,
+                int L, double alpha, void* stream);
 
 /* Per-step input preparation of the fused MNAR step in one launch: mask_p = mask * (U < keep_prob) (float masks,
  * create_missing_uci * mask, train.py:53-55; Philox counter = element index / 4 + offset), xin[0:B] = x * mask and,
- * when mask_p_out != NULL, xin[B:2B] = x * mask_p (the two encoder passes stacked).  If state != NULL, state[1]
- * (device) is added to the offset. */
+ * when mask_p_out != NULL, xin[B:2B] = x * mask_p (the two encoder passes stacked); when n_eps > 0 also
+ * eps_out[0:n_eps] ~ N(0,1) (counter offset_eps).  If state != NULL, state[1] (device) is added to both offsets:
+ * the per-step counter of a replayed HIP graph (bumped by vpc_nm_loss). */
 int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin, long B, int d, float keep_prob,
-                unsigned long long seed, unsigned long long offset, const long long* state, void* stream);
+                float* eps_out, long n_eps, unsigned long long seed, unsigned long long offset,
+                unsigned long long offset_eps, const long long* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -336,3 +336,26 @@ def test_harness_train_mnar(nm, tmp_path, monkeypatch):
                                      "exp", "kl_reg", vae_type, alpha=0.5, p_missingness=50)
         for (k, a), (_, b) in zip(model.state_dict().items(), again.state_dict().items()):
             assert torch.equal(a.cpu(), b.cpu()), k
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_graph_replay_equals_eager(nm, kind):
+    """step_graph (captured HIP graph, device-side step / RNG counters) is bit-identical to the eager sequence."""
+    cls = nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion
+    B, d, K = 128, 30, 8
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(B, d, device="cuda", generator=g)
+    m = (torch.rand(B, d, device="cuda", generator=g) < 0.6).float()
+    res = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(11)
+        model = cls(d, 500, 10, 6, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, lr=1e-3, seed=5)
+        losses = []
+        for s in range(6):
+            (tr.step if mode == "eager" else tr.step_graph)(x, m, alpha=0.5, p_missingness=50)
+            losses.append(tr.loss_value())
+        res.append((losses, model._flat.clone(), tr.epoch_total()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]

@@ -339,14 +339,20 @@ __global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __rest
     else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
 }
 
-// fused MNAR step: float mask_p draw + the stacked encoder input [x*mask ; x*mask_p]
+// fused MNAR step: float mask_p draw + the stacked encoder input [x*mask ; x*mask_p] (blocks [0, gm)) and the
+// step's normal draws (remaining blocks), one launch
 __global__ void nm_prep_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ mp,
-                               float* __restrict__ xin, long n, float keep_prob, uint64_t seed, uint64_t offset,
+                               float* __restrict__ xin, long n, float keep_prob, float* __restrict__ eps, long n_eps,
+                               uint64_t seed, uint64_t offset, uint64_t offset_eps, unsigned gm,
                                const long long* __restrict__ state) {
+    if (state) { offset += (uint64_t)state[1]; offset_eps += (uint64_t)state[1]; }
+    if (blockIdx.x >= gm) {
+        fill_normal_body(eps, n_eps, seed, offset_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
+        return;
+    }
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long i0 = g * 4;
     if (i0 >= n) return;
-    if (state) offset += (uint64_t)state[1];
     U4 r{0, 0, 0, 0};
     if (mp) r = philox((uint64_t)g + offset, 0u, seed);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
@@ -584,11 +590,13 @@ extern "C" int vpc_fill_normal(float* out, long n, unsigned long long seed, unsi
 }
 
 extern "C" int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin, long B, int d,
-                           float keep_prob, unsigned long long seed, unsigned long long offset, const long long* state,
+                           float keep_prob, float* eps_out, long n_eps, unsigned long long seed,
+                           unsigned long long offset, unsigned long long offset_eps, const long long* state,
                            void* stream) {
-    if (!x || !mask || !xin || B <= 0 || d <= 0) return VPC_ERR_ARG;
-    const long n = B * d, groups = (n + 3) / 4;
-    hipLaunchKernelGGL(nm_prep_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask,
-                       mask_p_out, xin, n, keep_prob, (uint64_t)seed, (uint64_t)offset, state);
+    if (!x || !mask || !xin || B <= 0 || d <= 0 || n_eps < 0 || (n_eps > 0 && !eps_out)) return VPC_ERR_ARG;
+    const long n = B * d, groups = (n + 3) / 4, ge = (n_eps + 3) / 4;
+    const unsigned gm = (unsigned)((groups + 255) / 256), gn = (unsigned)((ge + 255) / 256);
+    hipLaunchKernelGGL(nm_prep_kernel, dim3(gm + gn), dim3(256), 0, (hipStream_t)stream, x, mask, mask_p_out, xin, n,
+                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset, (uint64_t)offset_eps, gm, state);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }

@@ -255,6 +255,7 @@ struct NMFinArgs {
     float* gW; float* gb;   // [d] each (nullptr: skip)
     float* loss_f32;        // optional: out[0] as a float (slot of the data-parallel bucket)
     float* accum;           // optional: accum[0] += loss (epoch total, train.py:117, without a host sync)
+    long long* state; long long rng_inc;  // optional per-step counters of a replayed graph
     int accumulate;
     double inv_B;           // 1 / (rows the means run over): B, or the global batch under data parallelism
 };
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void nm_finalize_kernel(NMFinArgs a) {
         a.out[6] = red[0][0]; a.out[7] = red[0][1];
         if (a.loss_f32) a.loss_f32[0] = (float)a.out[0];
         if (a.accum) a.accum[0] += (float)a.out[0];
+        if (a.state) { a.state[0] += 1; a.state[1] += a.rng_inc; }
     }
 }
 
@@ -374,8 +376,8 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                 const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
                 float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
                 float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8,
-                float* loss_f32, float* accum, long B, long B_global, int K, int d, int L, double alpha,
-                void* stream) {
+                float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global, int K, int d,
+                int L, double alpha, void* stream) {
     const int reg = mask_p != nullptr;
     if (!x || !mask || !xm_q || !xl_q || !heads_q || !W || !b || !scratch || !out8) return VPC_ERR_ARG;
     if (B <= 0 || K <= 0 || B * (long)K > 0x7fffff00L || B_global < B) return VPC_ERR_ARG;
@@ -404,7 +406,7 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
     NMFinArgs f{};
     f.stat_part = a.stat_part; f.gwb_part = a.gwb_part; f.n_blocks = blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;
     f.alpha = al; f.reg = reg; f.out = out8; f.gW = grad ? gW : nullptr; f.gb = gb; f.accumulate = accumulate_wb;
-    f.loss_f32 = loss_f32; f.accum = accum;
+    f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
     f.inv_B = 1.0 / Bg;
     hipLaunchKernelGGL(nm_finalize_kernel, dim3(grad ? 1 + (2 * d + 63) / 64 : 1), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;

@@ -70,18 +70,21 @@ def nm_mul(x, mask, out):
     check(lib().vpc_nm_mul(ptr(x), ptr(mask), ptr(out), out.numel(), stream_ptr()), "vpc_nm_mul")
 
 
-def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, state=None):
-    check(lib().vpc_nm_prep(ptr(x), ptr(mask), ptr(mask_p_out), ptr(xin), B, d, float(keep_prob), int(seed), int(offset),
+def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, eps_out=None, offset_eps=0, state=None):
+    check(lib().vpc_nm_prep(ptr(x), ptr(mask), ptr(mask_p_out), ptr(xin), B, d, float(keep_prob), ptr(eps_out),
+                            0 if eps_out is None else eps_out.numel(), int(seed), int(offset), int(offset_eps),
                             ptr(state), stream_ptr()), "vpc_nm_prep")
 
 
 def nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, hq, hp, W, b, eps_kl, g_xm_q, g_xl_q, g_xm_p, g_xl_p,
-            ldg, ghq, ghp, gW, gb, xm_imp, scratch, out8, loss_f32, accum, B, B_global, K, d, Ld, alpha):
+            ldg, ghq, ghp, gW, gb, xm_imp, scratch, out8, loss_f32, accum, B, B_global, K, d, Ld, alpha, state=None,
+            rng_inc=0):
     check(lib().vpc_nm_loss(ptr(x), ptr(mask), ptr(mask_p), ptr(xm_q), ptr(xl_q), ldq, ptr(xm_p), ptr(xl_p), ldp,
                             ptr(hq), ptr(hp), 2 * Ld, ptr(W), ptr(b), ptr(eps_kl), ptr(g_xm_q), ptr(g_xl_q), ldg,
                             ptr(g_xm_p), ptr(g_xl_p), ldg, ptr(ghq), ptr(ghp), 2 * Ld, ptr(gW), ptr(gb), 0,
                             ptr(xm_imp), ptr(scratch), scratch.numel() * scratch.element_size(), ptr(out8),
-                            ptr(loss_f32), ptr(accum), B, B_global, K, d, Ld, float(alpha), stream_ptr()),
+                            ptr(loss_f32), ptr(accum), ptr(state), int(rng_inc), B, B_global, K, d, Ld, float(alpha),
+                            stream_ptr()),
           "vpc_nm_loss")
 
 
@@ -557,9 +560,9 @@ class NMTrainer:
         self.timers.setdefault(name, []).append((e0, e1))
         return r
 
-    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30):
+    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30, _state=None):
         """One optimiser step.  mask_p / eps ([2, B, K, L]: (eps_q, eps_p) or (eps, eps_kl)) may be injected for
-        parity tests; otherwise they are drawn on the device."""
+        parity tests; otherwise they are drawn on the device (one launch: mask_p + stacked encoder input + normals)."""
         m = self.model
         v = m._views()
         d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
@@ -572,20 +575,22 @@ class NMTrainer:
         P = 2 if reg else 1
         R, M, BK = P * B, P * B * K, B * K
         t = self._t
+        rng_inc = (2 * B * K * Ld + 3) // 4 + (B * d + 3) // 4
         # ---- inputs
         if reg and mask_p is not None:
             mp = _f32c(mask_p.reshape(-1, d))
             nm_mul(xf, mf, self.xin[:B])
             nm_mul(xf, mp, self.xin[B:])
+            if eps is None:
+                from .ops import fill_normal
+                fill_normal(self.eps, self.seed, self.rng_offset + (1 << 40))
         else:
             mp = self.mask_p if reg else None
-            t("prep", nm_prep, xf, mf, mp, self.xin, B, d, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset)
-        if eps is None:
-            from .ops import fill_normal
-            t("normal", fill_normal, self.eps, self.seed, self.rng_offset + (1 << 40))
-            self.rng_offset += (2 * B * K * Ld + 3) // 4 + (B * d + 3) // 4
-        else:
+            t("prep", nm_prep, xf, mf, mp, self.xin, B, d, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset,
+              self.eps if eps is None else None, self.rng_offset + (1 << 40), _state)
+        if eps is not None:
             self.eps.copy_(eps)
+        self.rng_offset += rng_inc
         # ---- forward
         t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU)
         t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU)
@@ -599,7 +604,8 @@ class NMTrainer:
         t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
           self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
           G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
-          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss, self.accum, B, Bg, K, d, Ld, alpha)
+          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss, self.accum, B, Bg, K, d, Ld, alpha,
+          _state, rng_inc)
         # ---- backward
         g = self.g
         gate = dict(y_gate=Y, gate=ACT_SIGMOID_HARDTANH, gate_split=d)
@@ -622,7 +628,42 @@ class NMTrainer:
         self.step_count += 1
         from .ops import adam_step
         t("adam", adam_step, m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-          self.betas[0], self.betas[1], self.eps_adam)
+          self.betas[0], self.betas[1], self.eps_adam, None, None, None if _state is None else _state[0:1])
+
+    def step_graph(self, x, mask, *, alpha=1.0, p_missingness=30):
+        """The same step replayed from a captured HIP graph (torch.cuda.CUDAGraph): ONE host call instead of ~30
+        launches.  Step count and Philox offsets live on the device (`state`), bumped by the loss kernel's finalize.
+        The first call with a new (shape, alpha, p_missingness) runs one eager step and captures.  Measured on
+        MI355X this removes the host cost but not the ~10 us dependent-dispatch latency per kernel node, so at
+        B = 128 it is no faster than step() (profiles/r01_notes.md).  Single process only."""
+        if self.world_size > 1:
+            return self.step(x, mask, alpha=alpha, p_missingness=p_missingness)
+        d = self.model.obs_dim
+        xf, mf = _f32c(x.reshape(-1, d)), _f32c(mask.reshape(-1, d))
+        L.require_cuda(xf, mf)
+        key = (tuple(xf.shape), float(alpha), p_missingness)
+        if getattr(self, "_graph_key", None) != key:
+            self.step(xf, mf, alpha=alpha, p_missingness=p_missingness)  # eager warm-up (LDS attributes, workspaces)
+            self._gx, self._gm = xf.clone(), mf.clone()
+            self.state = torch.tensor([self.step_count, 0], dtype=torch.int64, device=self.dev)
+            timers, self.timers = self.timers, None
+            base_rng, base_step = self.rng_offset, self.step_count
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step(self._gx, self._gm, alpha=alpha, p_missingness=p_missingness, _state=self.state)
+            self._graph_rng_inc = self.rng_offset - base_rng
+            self.rng_offset, self.step_count = base_rng, base_step  # capture executed nothing
+            self.timers = timers
+            self._graph, self._graph_key = g, key
+            return
+        if xf.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(xf)
+        if mf.data_ptr() != self._gm.data_ptr():
+            self._gm.copy_(mf)
+        self._graph.replay()
+        self.step_count += 1
+        self.rng_offset += self._graph_rng_inc
 
     def loss_value(self) -> float:
         return float(self.loss.item())
