@@ -214,7 +214,9 @@ int vpc_nm_mul(const float* x, const float* mask, float* out, long n, void* stre
  * writes the self-normalised imputation sum_k softmax(-l_w)_k x_mean[b][k] (llh_eval branch :2458-2461).
  * loss_f32 / accum (optional, device): loss as a float, and accum[0] += loss (train.py:117 without a host sync).
  * state (optional, two int64 on the device): state[0] += 1 (optimiser step count, read by vpc_adam_step's step_dev)
- * and state[1] += rng_inc (Philox counter offset read by vpc_nm_prep) - the per-step counters of a replayed graph. */
+ * and state[1] += rng_inc (Philox counter offset read by vpc_nm_prep) - the per-step counters of a replayed graph.
+ * gated != 0: g_xm / g_xl are gradients w.r.t. the head PRE-activations (already through Sigmoid' / Hardtanh'), so
+ * vpc_linear_dgrad / vpc_linear_wgrad take them with y_gate = NULL (the fused step; autograd callers pass 0). */
 int vpc_nm_loss_blocks(long B);
 long vpc_nm_loss_scratch(long B, int d);
 int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const float* xm_q, const float* xl_q, long ld_q,
@@ -222,8 +224,8 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                 const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
                 float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
                 float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8,
-                float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global, int K, int d,
-                int L, double alpha, void* stream);
+                float* loss_f32, float* accum, long long* state, long long rng_inc, int gated, long B, long B_global,
+                int K, int d, int L, double alpha, void* stream);
 
 /* Per-step input preparation of the fused MNAR step in one launch: mask_p = mask * (U < keep_prob) (float masks,
  * create_missing_uci * mask, train.py:53-55; Philox counter = element index / 4 + offset), xin[0:B] = x * mask and,

@@ -64,7 +64,7 @@ _PROTOS = {
     "vpc_nm_loss_blocks": [L_],
     "vpc_nm_loss_scratch": [L_, I],
     "vpc_nm_loss": [P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, I, P, P, L_, P,
-                    P, P, P, C.c_longlong, L_, L_, I, I, I, C.c_double, P],
+                    P, P, P, C.c_longlong, I, L_, L_, I, I, I, C.c_double, P],
     "vpc_nm_prep": [P, P, P, P, L_, I, F, P, L_, ULL, ULL, ULL, P, P],
 }
 _RESTYPE_LONG = {"vpc_linear_wgrad_scratch", "vpc_nm_loss_scratch"}

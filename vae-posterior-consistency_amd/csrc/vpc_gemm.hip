@@ -41,8 +41,11 @@ struct LinArgs {
 
 __device__ __forceinline__ float act_fwd(float v, int act, bool second) {
     switch (act) {
-        case ACT_ELU: return v > 0.f ? v : expm1f(v);
-        case ACT_SIGMOID_HARDTANH: return second ? fminf(fmaxf(v, -10.f), 0.f) : 1.f / (1.f + expf(-v));
+        // hardware exp / rcp (v_exp_f32, v_rcp_f32): |abs err| < 2e-7 on outputs in (-1, 1); the IEEE expm1f / expf +
+        // divide expansions cost ~40 VALU instructions per element, as much as the MFMAs of a K = 128 layer
+        case ACT_ELU: return v > 0.f ? v : __expf(v) - 1.f;
+        case ACT_SIGMOID_HARDTANH:
+            return second ? fminf(fmaxf(v, -10.f), 0.f) : __builtin_amdgcn_rcpf(1.f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
         default: return v;
     }
@@ -58,18 +61,20 @@ __device__ __forceinline__ float act_grad(float y, int act, bool second) {
 }
 
 constexpr int LIN_THREADS = 512;  // 8 waves: 4 (A-operand index) x 2 (B-operand index); a wave owns 32 x 64 outputs
-constexpr int LIN_TILE = 8192;    // floats per LDS tile
-constexpr int LIN_LD = LIN_TILE / 4 / LIN_THREADS;  // float4 loads per thread and tile (4)
-constexpr int IT = 2, JT = 4;     // 16 x 16 MFMA tiles per wave
+constexpr int LIN_TILE = 8192;    // floats per (full) LDS tile
+constexpr int IT = 2;             // 16 x 16 MFMA tiles per wave along the A-operand index
+// JT = tiles per wave along the B-operand index: 4 (128 B-rows per workgroup) or, for the forward / dgrad of SMALL
+// batches, 1 (32 batch rows per workgroup, 4x the workgroups: at the reference's batch 128 x K 20 a 128-row tiling
+// would occupy 40 of the 256 CUs)
 
 // ---- global -> registers: a ROWS x COLS tile (ROWS * COLS = 8192), zero-filled outside [rlim) x [clim)
-template <int COLS>
-__device__ __forceinline__ void gload(f32x4 (&r)[LIN_LD], const float* __restrict__ base, long ld, int r0, int c0,
+template <int COLS, int NLD>
+__device__ __forceinline__ void gload(f32x4 (&r)[NLD], const float* __restrict__ base, long ld, int r0, int c0,
                                       int rlim, int clim, int vec, const float* __restrict__ yg, long ldy, int gate,
                                       int gate_split) {
     constexpr int C4 = COLS / 4;
 #pragma unroll
-    for (int i = 0; i < LIN_LD; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         const int idx = threadIdx.x + LIN_THREADS * i;
         const int row = r0 + idx / C4, col = c0 + 4 * (idx % C4);
         f32x4 v = zero4();
@@ -100,11 +105,11 @@ __device__ __forceinline__ void gload(f32x4 (&r)[LIN_LD], const float* __restric
     }
 }
 // ---- registers -> swizzled LDS tile
-template <int COLS>
-__device__ __forceinline__ void sstore(float* __restrict__ s, const f32x4 (&r)[LIN_LD]) {
+template <int COLS, int NLD>
+__device__ __forceinline__ void sstore(float* __restrict__ s, const f32x4 (&r)[NLD]) {
     constexpr int C4 = COLS / 4;
 #pragma unroll
-    for (int i = 0; i < LIN_LD; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         const int idx = threadIdx.x + LIN_THREADS * i;
         const int row = idx / C4, sl = idx % C4;
         *reinterpret_cast<f32x4*>(s + row * COLS + ((sl ^ (row & 15)) << 2)) = r[i];
@@ -126,8 +131,12 @@ __device__ __forceinline__ f32x4 frag_T(const float* __restrict__ s, int ob, int
 }
 
 // RAGGED: some 16-wide tile of the layer is empty (L = 10, 2L = 20, d = 14 ...): skip those MFMAs (wave-uniform).
-template <int MODE, bool RAGGED>
+template <int MODE, bool RAGGED, int JT>
 __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
+    static_assert(JT == 4 || MODE != LIN_WGRAD, "the narrow tiling is for forward / dgrad only");
+    constexpr int BROWS = 32 * JT;                          // B-operand rows (batch rows) per workgroup
+    constexpr int NLA = LIN_TILE / 4 / LIN_THREADS;         // float4 loads per thread: A tile (4)
+    constexpr int NLB = BROWS * 64 / 4 / LIN_THREADS;       //                          B tile (4 or 1)
     extern __shared__ __align__(16) float lds[];
     float* sA = lds;
     float* sB = lds + LIN_TILE;
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
     // output tile origin (i0 along the A-operand index, j0 along the B-operand index) and contraction range
     int i0, j0, k_begin, k_end, ilim, jlim;
     if (MODE == LIN_FWD) {
-        j0 = blockIdx.x * 128; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.K; ilim = a.N; jlim = a.M;
+        j0 = blockIdx.x * BROWS; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.K; ilim = a.N; jlim = a.M;
     } else if (MODE == LIN_DGRAD) {
-        j0 = blockIdx.x * 128; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.N; ilim = a.K; jlim = a.M;
+        j0 = blockIdx.x * BROWS; i0 = blockIdx.y * 128; k_begin = 0; k_end = a.N; ilim = a.K; jlim = a.M;
     } else {
         i0 = blockIdx.y * 128; j0 = blockIdx.z * 128; ilim = a.N; jlim = a.K;
         k_begin = blockIdx.x * a.rows_per_split;
@@ -158,25 +167,25 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
         for (int j = 0; j < JT; ++j) acc[i][j] = zero4();
     float bsum = 0.f;  // wgrad: column sum of dY~ (bias gradient), threads 0..127 of the k-tile-0 workgroups
 
-    f32x4 ra[LIN_LD], rb[LIN_LD];
+    f32x4 ra[NLA], rb[NLB];
     auto load_chunk = [&](int k0) {
         if (MODE == LIN_FWD) {
-            gload<64>(ra, a.A, a.lda, i0, k0, a.N, k_end, a.vecA, nullptr, 0, 0, 0);
-            gload<64>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, nullptr, 0, 0, 0);
+            gload<64, NLA>(ra, a.A, a.lda, i0, k0, a.N, k_end, a.vecA, nullptr, 0, 0, 0);
+            gload<64, NLB>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, nullptr, 0, 0, 0);
         } else if (MODE == LIN_DGRAD) {
-            gload<128>(ra, a.A, a.lda, k0, i0, k_end, a.K, a.vecA, nullptr, 0, 0, 0);
-            gload<64>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, a.Yg, a.ldy, a.gate, a.gate_split);
+            gload<128, NLA>(ra, a.A, a.lda, k0, i0, k_end, a.K, a.vecA, nullptr, 0, 0, 0);
+            gload<64, NLB>(rb, a.B, a.ldb, j0, k0, a.M, k_end, a.vecB, a.Yg, a.ldy, a.gate, a.gate_split);
         } else {
-            gload<128>(ra, a.A, a.lda, k0, i0, k_end, a.N, a.vecA, a.Yg, a.ldy, a.gate, a.gate_split);
-            gload<128>(rb, a.B, a.ldb, k0, j0, k_end, a.K, a.vecB, nullptr, 0, 0, 0);
+            gload<128, NLA>(ra, a.A, a.lda, k0, i0, k_end, a.N, a.vecA, a.Yg, a.ldy, a.gate, a.gate_split);
+            gload<128, NLB>(rb, a.B, a.ldb, k0, j0, k_end, a.K, a.vecB, nullptr, 0, 0, 0);
         }
     };
 
     if (k_begin < k_end) load_chunk(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += 64) {
         __syncthreads();
-        sstore<AT ? 128 : 64>(sA, ra);
-        sstore<BT ? 128 : 64>(sB, rb);
+        sstore<AT ? 128 : 64, NLA>(sA, ra);
+        sstore<BT ? 128 : 64, NLB>(sB, rb);
         __syncthreads();
         if (k0 + 64 < k_end) load_chunk(k0 + 64);
         if (MODE == LIN_WGRAD && blockIdx.z == 0 && threadIdx.x < 128) {
@@ -286,33 +295,41 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float*
                                     int K, float* __restrict__ dW, float* __restrict__ db, int accumulate) {
     const long n_w = (long)N * K;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_w) {
-        float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += part[(long)sp * n_w + i];
-        dW[i] = accumulate ? dW[i] + s : s;
-    } else if (i < n_w + N) {
-        const int n = (int)(i - n_w);
-        float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += bias_part[(long)sp * N + n];
-        if (db) db[n] = accumulate ? db[n] + s : s;
+    if (i >= n_w + N) return;
+    const bool is_w = i < n_w;
+    const float* src = is_w ? part + i : bias_part + (i - n_w);
+    const long stride = is_w ? n_w : N;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // 4 interleaved chains (fixed association => deterministic)
+    int sp = 0;
+    for (; sp + 3 < S; sp += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += src[(long)(sp + u) * stride];
     }
+    for (; sp < S; ++sp) acc[0] += src[(long)sp * stride];
+    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float* dst = is_w ? dW + i : (db ? db + (i - n_w) : nullptr);
+    if (dst) *dst = accumulate ? *dst + s : s;
 }
 
 static bool vec_ok(const void* p, long ld) { return aligned16(p) && (ld % 4) == 0; }
 
+template <int MODE, bool RAGGED, int JT>
+static int launch_one(const LinArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t LDS = (LIN_TILE + (MODE == LIN_WGRAD ? LIN_TILE : 32 * JT * 64)) * sizeof(float);
+    if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, RAGGED, JT>), LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL((linear_kernel<MODE, RAGGED, JT>), grid, dim3(LIN_THREADS), LDS, st, a);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+// forward / dgrad: grid.x over batch rows (128 or 32 per workgroup), grid.y over 128 output features
 template <int MODE>
-static int launch(const LinArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t LDS = 2 * LIN_TILE * sizeof(float);
+static int launch_rows(const LinArgs& a, int out_features, hipStream_t st) {
     // feature dimensions that leave whole 16-wide tiles / contraction sub-blocks empty take the tile-skipping build
     const bool ragged = (a.N % 64) != 0 || (a.K % 64) != 0;
-    if (ragged) {
-        if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, true>), LDS)) return VPC_ERR_HIP;
-        hipLaunchKernelGGL((linear_kernel<MODE, true>), grid, dim3(LIN_THREADS), LDS, st, a);
-    } else {
-        if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, false>), LDS)) return VPC_ERR_HIP;
-        hipLaunchKernelGGL((linear_kernel<MODE, false>), grid, dim3(LIN_THREADS), LDS, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+    const unsigned gy = (unsigned)((out_features + 127) / 128);
+    const bool narrow = (long)((a.M + 127) / 128) * gy < 2L * num_cus();
+    const unsigned gx = (unsigned)((a.M + (narrow ? 31 : 127)) / (narrow ? 32 : 128));
+    if (narrow) return ragged ? launch_one<MODE, true, 1>(a, dim3(gx, gy), st) : launch_one<MODE, false, 1>(a, dim3(gx, gy), st);
+    return ragged ? launch_one<MODE, true, 4>(a, dim3(gx, gy), st) : launch_one<MODE, false, 4>(a, dim3(gx, gy), st);
 }
 
 }  // namespace vpc
@@ -329,7 +346,7 @@ int vpc_linear_fwd(const float* x, long ldx, const float* w, const float* bias, 
     a.A = w; a.lda = K; a.B = x; a.ldb = ldx; a.C = y; a.ldc = ldy; a.bias = bias;
     a.M = (int)M; a.N = N; a.K = K; a.act = act; a.split = act == ACT_SIGMOID_HARDTANH ? act_split : N;
     a.vecA = vec_ok(w, K); a.vecB = vec_ok(x, ldx); a.vecC = vec_ok(y, ldy);
-    return launch<LIN_FWD>(a, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128)), (hipStream_t)stream);
+    return launch_rows<LIN_FWD>(a, N, (hipStream_t)stream);
 }
 
 int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
@@ -344,7 +361,7 @@ int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     a.M = (int)M; a.N = N; a.K = K;
     a.vecA = vec_ok(w, K); a.vecB = vec_ok(dy, lddy) && (!y_gate || vec_ok(y_gate, ldyg)); a.vecC = vec_ok(dx, lddx);
     a.vecX = x_out && vec_ok(x_out, ldx);
-    return launch<LIN_DGRAD>(a, dim3((unsigned)((M + 127) / 128), (unsigned)((K + 127) / 128)), (hipStream_t)stream);
+    return launch_rows<LIN_DGRAD>(a, K, (hipStream_t)stream);
 }
 
 long vpc_linear_wgrad_scratch(long M, int N, int K) {
@@ -375,7 +392,9 @@ int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     a.M = (int)M; a.N = N; a.K = K; a.rows_per_split = (int)rows_per_split;
     a.vecA = vec_ok(dy, lddy) && (!y_gate || vec_ok(y_gate, ldyg)); a.vecB = vec_ok(x, ldx);
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch<LIN_WGRAD>(a, dim3((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128)), st);
+    const dim3 grid((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
+    const bool ragged = (N % 64) != 0 || (K % 64) != 0;
+    int rc = ragged ? launch_one<LIN_WGRAD, true, 4>(a, grid, st) : launch_one<LIN_WGRAD, false, 4>(a, grid, st);
     if (rc != VPC_OK) return rc;
     const long n = (long)N * K + N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch,

@@ -33,6 +33,7 @@ struct NMLossArgs {
     int B, K, d, L;
     float oq, op, oe, cr;                                    // gradient weights: (1-a)/B, a/B, a/(BK), a/(BL)
     float kq, kp;                                            // weights of the analytic KL gradients: (1-a)/B, a/B
+    int gated;                                               // gradients w.r.t. the head PRE-activations
 };
 constexpr int NM_STATS = 5;  // sums over rows of: lse_q, lse_p, sum_k RE_e, sum_l kl_el, sum_k RE_q
 
@@ -53,7 +54,9 @@ struct Lse {  // online log-sum-exp
     __device__ __forceinline__ float value() const { return mx + logf(s); }
 };
 
-template <int T, bool REG>
+// PF: fetch sample k+1 while sample k is reduced (small batches: one row per wave, nothing else hides the latency;
+// at large batches the extra registers cost occupancy and the other waves hide it anyway)
+template <int T, bool REG, bool PF>
 __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
     extern __shared__ __align__(8) float lds[];
     double* stat_sh = reinterpret_cast<double*>(lds);   // [4 waves][NM_STATS]
@@ -115,41 +118,55 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             sd_q = expf(0.5f * lv_q);
         }
 
-        // per-(b,k) terms; returns l_w_q and l_w_p, leaves the element-wise pieces in the out arrays
-        auto terms = [&](int k, float& lwq, float& lwp, float& re_q_out, float& re_e_out, float (&riv)[T],
-                         float (&hq2)[T], float (&dn)[T], float (&mix)[T], float (&rivp)[T], float (&hp2)[T],
-                         float& z_out, float& e_out) {
+        // the decoder outputs of sample k, fetched one sample ahead of their use (the loads of k+1 fly while k is
+        // reduced: a wave has nothing else to overlap its HBM latency with)
+        struct Fetch { float xm[T], xl[T], xmp[T], xlp[T], e; };
+        auto fetch = [&](int k, Fetch& f) {
             const long row = (long)b * K + k;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = lane + 64 * t;
+                const bool ok = j < d;
+                f.xm[t] = ok ? a.xm_q[row * a.ld_q + j] : 0.f;
+                f.xl[t] = ok ? a.xl_q[row * a.ld_q + j] : 0.f;
+                if (REG) {
+                    f.xmp[t] = ok ? a.xm_p[row * a.ld_p + j] : 0.f;
+                    f.xlp[t] = ok ? a.xl_p[row * a.ld_p + j] : 0.f;
+                }
+            }
+            if (!REG) f.e = lok ? a.eps_kl[row * L + lane] : 0.f;
+        };
+        // per-(b,k) terms; returns l_w_q and l_w_p, leaves the element-wise pieces in the out arrays
+        auto terms = [&](const Fetch& f, float& lwq, float& lwp, float& re_q_out, float& re_e_out, float (&riv)[T],
+                         float (&dn)[T], float (&rivp)[T], float& z_out, float& e_out) {
             float s_req = 0.f, s_nlp = 0.f, s_ree = 0.f, s_rep = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int j = lane + 64 * t;
                 const bool ok = j < d;
-                const float xm = ok ? a.xm_q[row * a.ld_q + j] : 0.f;
-                const float xl = ok ? a.xl_q[row * a.ld_q + j] : 0.f;
+                const float xm = f.xm[t];
+                const float xl = f.xl[t];
                 const float iv = fexp(-xl), r = x[t] - xm;
                 riv[t] = r * iv;                       // (x - xm) / var
-                hq2[t] = 0.5f - 0.5f * r * riv[t];     // d/dxl of the element NLL
                 const float el = 0.5f * xl + 0.5f * r * riv[t];
                 s_req += m[t] * el;
                 if (REG) s_ree += m[t] * (1.f - mp[t]) * el;
-                mix[t] = xm * (1.f - m[t]) + x[t] * m[t];
-                const float lg = -sp[t] * (mix[t] - bj[t]);
+                const float mixv = xm * (1.f - m[t]) + x[t] * m[t];
+                const float lg = -sp[t] * (mixv - bj[t]);
                 const float el2 = fexp(-fabsf(lg)), rc = frcp(1.f + el2);
                 s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + __logf(1.f + el2) : 0.f;
                 dn[t] = (lg >= 0.f ? rc : el2 * rc) - m[t];
                 if (REG) {
-                    const float xmp = ok ? a.xm_p[row * a.ld_p + j] : 0.f;
-                    const float xlp = ok ? a.xl_p[row * a.ld_p + j] : 0.f;
+                    const float xmp = f.xmp[t];
+                    const float xlp = f.xlp[t];
                     const float ivp = fexp(-xlp), rp = x[t] - xmp;
                     rivp[t] = rp * ivp;
-                    hp2[t] = 0.5f - 0.5f * rp * rivp[t];
                     s_rep += mp[t] * (0.5f * xlp + 0.5f * rp * rivp[t]);
                 }
             }
             float KL = KLq;
             if (!REG) {
-                const float e = lok ? a.eps_kl[row * L + lane] : 0.f;
+                const float e = f.e;
                 const float z = mu_q + e * sd_q;
                 z_out = z; e_out = e;
                 KL = wave_sum_dpp(lok ? -0.5f * e * e - 0.5f * lv_q + 0.5f * z * z : 0.f);
@@ -167,10 +184,14 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
         // ---- pass 1: log-sum-exp of +l_w (both passes) and of -l_w (imputation weights)
         Lse lq, lp, ln;
         float sum_ree = 0.f, sum_req = 0.f;
-        float riv[T], hq2[T], dn[T], mix[T], rivp[T], hp2[T];
+        float riv[T], dn[T], rivp[T];
+        Fetch cur, nxt;
+        if (PF) fetch(0, cur);
         for (int k = 0; k < K; ++k) {
+            if (PF) { if (k + 1 < K) fetch(k + 1, nxt); } else fetch(k, cur);
             float lwq, lwp = 0.f, req, ree = 0.f, z, e;
-            terms(k, lwq, lwp, req, ree, riv, hq2, dn, mix, rivp, hp2, z, e);
+            terms(cur, lwq, lwp, req, ree, riv, dn, rivp, z, e);
+            if (PF) cur = nxt;
             lq.add(lwq); ln.add(-lwq);
             if (REG) { lp.add(lwp); sum_ree += ree; }
             sum_req += req;
@@ -183,19 +204,18 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
         float imp[T], dmu = 0.f, dlv = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) imp[t] = 0.f;
+        if (PF) fetch(0, cur);
         for (int k = 0; k < K; ++k) {
+            if (PF) { if (k + 1 < K) fetch(k + 1, nxt); } else fetch(k, cur);
             float lwq, lwp = 0.f, req, ree = 0.f, z = 0.f, e = 0.f;
-            terms(k, lwq, lwp, req, ree, riv, hq2, dn, mix, rivp, hp2, z, e);
+            terms(cur, lwq, lwp, req, ree, riv, dn, rivp, z, e);
             const long row = (long)b * K + k;
             if (a.xm_imp) {
                 const float wi = fexp(-lwq - lse_n);
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int j = lane + 64 * t;
-                    if (j < d) imp[t] += wi * a.xm_q[row * a.ld_q + j];
-                }
+                for (int t = 0; t < T; ++t) imp[t] += wi * cur.xm[t];
             }
-            if (!grad) continue;
+            if (!grad) { if (PF) cur = nxt; continue; }
             const float wq = a.oq * fexp(lwq - lse_q);
             const float wp = REG ? a.op * fexp(lwp - lse_p) : 0.f;
 #pragma unroll
@@ -203,16 +223,32 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 const int j = lane + 64 * t;
                 if (j >= d) continue;
                 const float ee = REG ? a.oe * m[t] * (1.f - mp[t]) : 0.f;
-                a.g_xm_q[row * a.ldg_q + j] = wq * (-m[t] * riv[t] - dn[t] * sp[t] * (1.f - m[t])) - ee * riv[t];
-                a.g_xl_q[row * a.ldg_q + j] = (wq * m[t] + ee) * hq2[t];
-                gW[t] -= wq * dn[t] * sg[t] * (mix[t] - bj[t]);
+                // recomputed rather than carried out of terms(): registers decide the occupancy of this kernel
+                const float hq2 = 0.5f - 0.5f * (x[t] - cur.xm[t]) * riv[t];  // d/dxl of the element NLL
+                const float mixv = cur.xm[t] * (1.f - m[t]) + x[t] * m[t];
+                float gxm = wq * (-m[t] * riv[t] - dn[t] * sp[t] * (1.f - m[t])) - ee * riv[t];
+                float gxl = (wq * m[t] + ee) * hq2;
+                if (a.gated) {  // through Sigmoid / Hardtanh(-10, 0): the backward GEMMs then need no gate pass
+                    gxm *= cur.xm[t] * (1.f - cur.xm[t]);
+                    gxl = (cur.xl[t] > -10.f && cur.xl[t] < 0.f) ? gxl : 0.f;
+                }
+                a.g_xm_q[row * a.ldg_q + j] = gxm;
+                a.g_xl_q[row * a.ldg_q + j] = gxl;
+                gW[t] -= wq * dn[t] * sg[t] * (mixv - bj[t]);
                 gB[t] += wq * dn[t] * sp[t];
                 if (REG) {
-                    a.g_xm_p[row * a.ldg_p + j] = -wp * mp[t] * rivp[t];
-                    a.g_xl_p[row * a.ldg_p + j] = wp * mp[t] * hp2[t];
+                    const float hp2 = 0.5f - 0.5f * (x[t] - cur.xmp[t]) * rivp[t];
+                    float gxmp = -wp * mp[t] * rivp[t], gxlp = wp * mp[t] * hp2;
+                    if (a.gated) {
+                        gxmp *= cur.xmp[t] * (1.f - cur.xmp[t]);
+                        gxlp = (cur.xlp[t] > -10.f && cur.xlp[t] < 0.f) ? gxlp : 0.f;
+                    }
+                    a.g_xm_p[row * a.ldg_p + j] = gxmp;
+                    a.g_xl_p[row * a.ldg_p + j] = gxlp;
                 }
             }
             if (!REG) { dmu += wq * z; dlv += wq * (-0.5f + 0.5f * z * e * sd_q); }
+            if (PF) cur = nxt;
         }
         if (a.xm_imp) {
 #pragma unroll
@@ -344,12 +380,31 @@ __global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restri
     if (i < n) o[i] = x[i] * m[i];
 }
 
-template <int T>
-static int launch_loss(const NMLossArgs& a, int reg, int n_blocks, hipStream_t st) {
-    const size_t lds = (2 * 4 * NM_STATS + 3 * (size_t)a.d + 4 * 2 * (size_t)a.d) * sizeof(float);
-    if (reg) hipLaunchKernelGGL((nm_loss_kernel<T, true>), dim3(n_blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((nm_loss_kernel<T, false>), dim3(n_blocks), dim3(256), lds, st, a);
+// The rows are walked by a grid-stride loop, so the grid is sized to ONE resident round of the variant actually
+// launched (its register count decides 2 - 6 workgroups per CU): a grid of 4 workgroups per CU on a kernel that fits
+// 3 runs two rounds and doubles the time at mid-size batches.
+template <int T, bool REG, bool PF>
+static int launch_variant(const NMLossArgs& a, int* n_blocks, size_t lds, hipStream_t st) {
+    static int occ = 0;  // per variant
+    if (occ == 0) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, nm_loss_kernel<T, REG, PF>, 256, lds) != hipSuccess || o < 1)
+            o = 1;
+        occ = o;
+    }
+    const long cap = (long)occ * num_cus();
+    if (*n_blocks > cap) *n_blocks = (int)cap;
+    hipLaunchKernelGGL((nm_loss_kernel<T, REG, PF>), dim3(*n_blocks), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+template <int T>
+static int launch_loss(const NMLossArgs& a, int reg, int* n_blocks, hipStream_t st) {
+    const size_t lds = (2 * 4 * NM_STATS + 3 * (size_t)a.d + 4 * 2 * (size_t)a.d) * sizeof(float);
+    const bool pf = (long)a.B < 16L * num_cus();  // fewer rows than resident waves
+    if (reg && pf) return launch_variant<T, true, true>(a, n_blocks, lds, st);
+    if (reg) return launch_variant<T, true, false>(a, n_blocks, lds, st);
+    if (pf) return launch_variant<T, false, true>(a, n_blocks, lds, st);
+    return launch_variant<T, false, false>(a, n_blocks, lds, st);
 }
 
 }  // namespace vpc
@@ -360,7 +415,7 @@ extern "C" {
 
 int vpc_nm_loss_blocks(long B) {
     long blocks = (B + 3) / 4;
-    const long cap = 4L * num_cus();  // one resident round at 4 waves / SIMD; the rest is a grid-stride loop
+    const long cap = 8L * num_cus();  // upper bound of one resident round (the launch trims it to the variant's occupancy)
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -376,8 +431,8 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
                 const float* W, const float* b, const float* eps_kl, float* g_xm_q, float* g_xl_q, long ldg_q,
                 float* g_xm_p, float* g_xl_p, long ldg_p, float* g_heads_q, float* g_heads_p, long ldgh, float* gW,
                 float* gb, int accumulate_wb, float* xm_imp, void* scratch, long scratch_bytes, double* out8,
-                float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global, int K, int d,
-                int L, double alpha, void* stream) {
+                float* loss_f32, float* accum, long long* state, long long rng_inc, int gated, long B, long B_global,
+                int K, int d, int L, double alpha, void* stream) {
     const int reg = mask_p != nullptr;
     if (!x || !mask || !xm_q || !xl_q || !heads_q || !W || !b || !scratch || !out8) return VPC_ERR_ARG;
     if (B <= 0 || K <= 0 || B * (long)K > 0x7fffff00L || B_global < B) return VPC_ERR_ARG;
@@ -387,7 +442,7 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
     const bool grad = g_xm_q != nullptr;
     if (grad && (!g_xl_q || !g_heads_q || !gW || !gb || (reg && (!g_xm_p || !g_xl_p || !g_heads_p)))) return VPC_ERR_ARG;
     if (scratch_bytes < vpc_nm_loss_scratch(B, d) || (reinterpret_cast<uintptr_t>(scratch) & 7)) return VPC_ERR_ARG;
-    const int blocks = vpc_nm_loss_blocks(B);
+    int blocks = vpc_nm_loss_blocks(B);  // upper bound (sizes the scratch); the launch may use fewer
     NMLossArgs a{};
     a.x = x; a.m = mask; a.mp = mask_p; a.xm_q = xm_q; a.xl_q = xl_q; a.ld_q = ld_q; a.xm_p = xm_p; a.xl_p = xl_p;
     a.ld_p = ld_p; a.hq = heads_q; a.hp = heads_p; a.ldh = ldh; a.W = W; a.b = b; a.eps_kl = eps_kl;
@@ -398,10 +453,10 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
     a.B = (int)B; a.K = K; a.d = d; a.L = L;
     const double al = reg ? alpha : 0.0, Bg = (double)B_global;
     a.oq = (float)((1.0 - al) / Bg); a.op = (float)(al / Bg); a.oe = (float)(al / (Bg * K)); a.cr = (float)(al / (Bg * L));
-    a.kq = a.oq; a.kp = a.op;
+    a.kq = a.oq; a.kp = a.op; a.gated = gated;
     hipStream_t st = (hipStream_t)stream;
-    int rc = d <= 64 ? launch_loss<1>(a, reg, blocks, st) : d <= 128 ? launch_loss<2>(a, reg, blocks, st)
-                                                                      : launch_loss<4>(a, reg, blocks, st);
+    int rc = d <= 64 ? launch_loss<1>(a, reg, &blocks, st) : d <= 128 ? launch_loss<2>(a, reg, &blocks, st)
+                                                                       : launch_loss<4>(a, reg, &blocks, st);
     if (rc != VPC_OK) return rc;
     NMFinArgs f{};
     f.stat_part = a.stat_part; f.gwb_part = a.gwb_part; f.n_blocks = blocks; f.B = (int)B; f.K = K; f.d = d; f.L = L;

@@ -78,13 +78,13 @@ def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, eps_out=Non
 
 def nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, hq, hp, W, b, eps_kl, g_xm_q, g_xl_q, g_xm_p, g_xl_p,
             ldg, ghq, ghp, gW, gb, xm_imp, scratch, out8, loss_f32, accum, B, B_global, K, d, Ld, alpha, state=None,
-            rng_inc=0):
+            rng_inc=0, gated=False):
     check(lib().vpc_nm_loss(ptr(x), ptr(mask), ptr(mask_p), ptr(xm_q), ptr(xl_q), ldq, ptr(xm_p), ptr(xl_p), ldp,
                             ptr(hq), ptr(hp), 2 * Ld, ptr(W), ptr(b), ptr(eps_kl), ptr(g_xm_q), ptr(g_xl_q), ldg,
                             ptr(g_xm_p), ptr(g_xl_p), ldg, ptr(ghq), ptr(ghp), 2 * Ld, ptr(gW), ptr(gb), 0,
                             ptr(xm_imp), ptr(scratch), scratch.numel() * scratch.element_size(), ptr(out8),
-                            ptr(loss_f32), ptr(accum), ptr(state), int(rng_inc), B, B_global, K, d, Ld, float(alpha),
-                            stream_ptr()),
+                            ptr(loss_f32), ptr(accum), ptr(state), int(rng_inc), int(gated), B, B_global, K, d, Ld,
+                            float(alpha), stream_ptr()),
           "vpc_nm_loss")
 
 
@@ -605,12 +605,11 @@ class NMTrainer:
           self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
           G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
           self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss, self.accum, B, Bg, K, d, Ld, alpha,
-          _state, rng_inc)
-        # ---- backward
+          _state, rng_inc, True)
+        # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
         g = self.g
-        gate = dict(y_gate=Y, gate=ACT_SIGMOID_HARDTANH, gate_split=d)
-        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID, **gate)
-        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, **gate)
+        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID)
+        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU)
         t("dec_wgrad2", linear_wgrad, self.dg2, self.g1, g["Wd2"], g["bd2"], M, HID, HID)
         t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU)
         t("dec_wgrad1", linear_wgrad, self.dg1, self.z, g["Wd1"], g["bd1"], M, HID, Ld)
