@@ -143,3 +143,67 @@ def test_two_rank_fused_trainer_matches_single_process():
         assert abs(tr.loss_value() - losses2[i]) <= 2e-6 * abs(losses2[i])
     flat1 = m._flat.cpu().numpy()
     assert np.max(np.abs(flat1 - flat2)) <= 2e-6 * np.max(np.abs(flat1))
+
+
+# ----------------------------------------------------------------------------------------------- MNAR path, 2 ranks
+def _nm_inputs(B, d, K, Ld, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, d, generator=g)
+    mask = (torch.rand(B, d, generator=g) < 0.7).float()
+    mask_p = mask * (torch.rand(B, d, generator=g) < 0.5).float()
+    eps = torch.randn(2, B, K, Ld, generator=g)
+    return x, mask, mask_p, eps
+
+
+def _nm_model(d, K, Ld, B):
+    torch.manual_seed(17)
+    return vpc.REG_notMIWAE_v2(d, 128, 10, Ld, {"batch_size": B, "patience": 1}, K, 1)
+
+
+def _nm_gpu_worker(rank, world, port, d, B, K, Ld, steps, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    vpc.dp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    m = _nm_model(d, K, Ld, B).to(dev)
+    vpc.dp.broadcast_parameters(m.flatten_parameters())
+    tr = vpc.NMTrainer(m, world_size=world)
+    x, mask, mask_p, eps = _nm_inputs(B, d, K, Ld)
+    lo, hi = vpc.dp.shard_rows(B, rank, world)
+    losses = []
+    for i in range(steps):
+        tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eps[:, lo:hi].contiguous().to(dev),
+                alpha=0.5, global_batch=B)
+        losses.append(tr.loss_value())
+    if rank == 0:
+        out.put((losses, m._flat.cpu().numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_mnar_trainer_matches_single_process():
+    """NMTrainer under data parallelism: ONE all-reduce of [grads | loss], every term normalised by the global batch,
+    equals the single-process step on the concatenated batch (uneven shards: 300 rows -> 150 + 150, K = 5)."""
+    d, B, K, Ld, steps = 40, 300, 5, 6, 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nm_gpu_worker, args=(r, 2, port, d, B, K, Ld, steps, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses2, flat2 = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    m = _nm_model(d, K, Ld, B).to(dev)
+    tr = vpc.NMTrainer(m)
+    x, mask, mask_p, eps = _nm_inputs(B, d, K, Ld)
+    for i in range(steps):
+        tr.step(x.to(dev), mask.to(dev), mask_p.to(dev), eps.to(dev), alpha=0.5)
+        assert abs(tr.loss_value() - losses2[i]) <= 5e-6 * abs(losses2[i]), (i, tr.loss_value(), losses2[i])
+    flat1 = m._flat.cpu().numpy()
+    # sharding changes the fp32 summation order of the weight gradients; Adam's m / sqrt(v) turns a 1e-7 relative
+    # difference of a tiny gradient into up to lr = 1e-3 per step, so parameters are compared at 3e-5 of their scale
+    assert np.max(np.abs(flat1 - flat2)) <= 3e-5 * np.max(np.abs(flat1))

@@ -560,7 +560,7 @@ class NMTrainer:
         self.timers.setdefault(name, []).append((e0, e1))
         return r
 
-    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30, _state=None):
+    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30, global_batch=None, _state=None):
         """One optimiser step.  mask_p / eps ([2, B, K, L]: (eps_q, eps_p) or (eps, eps_kl)) may be injected for
         parity tests; otherwise they are drawn on the device (one launch: mask_p + stacked encoder input + normals)."""
         m = self.model
@@ -569,7 +569,7 @@ class NMTrainer:
         xf, mf = _f32c(x.reshape(-1, d)), _f32c(mask.reshape(-1, d))
         L.require_cuda(xf, mf)
         B = xf.shape[0]
-        Bg = B * self.world_size
+        Bg = global_batch or B * self.world_size  # every rank normalises by the GLOBAL batch: SUM over ranks = result
         self._ws(B)
         reg = self.reg
         P = 2 if reg else 1
