@@ -1,0 +1,148 @@
+"""GPU parity of the PNP / EDDI family through the C ABI, against vectors captured from
+the reference itself (tests/golden/eddi_*.npz) and the float64 folded closed form of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ed():
+    import vpc_amd
+    from vpc_amd import eddi
+    return eddi
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def _load(g, cls, *extra, prefix="param."):
+    d = g["x"].shape[1]
+    model = cls(d, 500, int(g["K"]), int(g["L"]), {"batch_size": 64, "patience": 1}, "exp", *extra)
+    model.load_state_dict({k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith(prefix)})
+    return model.cuda()
+
+
+def _grad_check(model, g, tag, tol=2e-4):
+    for k, p in model.named_parameters():
+        ref = g.get(f"grad.{tag}.{k}")
+        if ref is None:
+            continue
+        assert p.grad is not None, k
+        _close(p.grad, torch.from_numpy(ref), tol, f"grad {k}")
+
+
+@pytest.mark.parametrize("B,d,K", [(1, 14, 10), (37, 40, 20), (300, 128, 32), (513, 100, 7)])
+def test_front_end_vs_closed_form(ed, B, d, K):
+    from oracle import eddi_oracle as O
+    rng = np.random.default_rng(B + d)
+    x = rng.random((B, d), dtype=np.float32)
+    m = rng.random((B, d)) < 0.6
+    E, tb = rng.normal(size=(d, K)).astype(np.float32), rng.normal(size=(d, 1)).astype(np.float32)
+    Wp, cp = rng.normal(size=(K, 2 + K)).astype(np.float32) * 0.3, rng.normal(size=K).astype(np.float32) * 0.3
+    dagg = rng.normal(size=(B, K)).astype(np.float32)
+    agg_ref, gr = O.front_closed_form(x, m, E, tb, Wp, cp, dagg)
+    AC = torch.empty(2, K, d, device="cuda")
+    ed.eddi_fold(_dev(E), _dev(tb), _dev(Wp), _dev(cp), AC, d, K)
+    agg = torch.full((B, K), float("nan"), device="cuda")
+    mu8 = _dev(m.astype(np.uint8))
+    ed.eddi_front_fwd(_dev(x), mu8, AC, agg, B, d, K)
+    _close(agg, torch.from_numpy(agg_ref), 1e-5, "agg")
+    gE, gtb, gWp, gcp = (torch.full(s, float("nan"), device="cuda") for s in ((d, K), (d, 1), (K, 2 + K), (K,)))
+    ed.eddi_front_bwd(_dev(x), mu8, AC, _dev(dagg), _dev(E), _dev(tb), _dev(Wp), gE, gtb, gWp, gcp, B, d, K)
+    for got, key in ((gE, "type_pars1"), (gtb, "type_bias1"), (gWp, "pnp_encoder1.0.weight"), (gcp, "pnp_encoder1.0.bias")):
+        _close(got, torch.from_numpy(gr[key]), 2e-5, key)
+
+
+@pytest.mark.parametrize("d", [14, 40])
+def test_reg_eddi_against_reference(ed, d):
+    g = load_golden(f"eddi_reg_d{d}.npz")
+    x, m, mp = _dev(g["x"]), _dev(g["mask"]), _dev(g["mask_p"])
+    names = ["mean_p", "logvar_p", "x_mean_p", "x_logvar_p", "mean_q", "logvar_q", "x_mean_q", "x_logvar_q"]
+    for tag, rt, alpha in (("kl0.5", "kl_reg", 0.5), ("kl1.0", "kl_reg", 1.0), ("ml0.8", "ml_reg", 0.8)):
+        model = _load(g, ed.Reg_EDDI, rt)
+        torch.manual_seed(0)
+        # inject the reference's eps through torch.randn's stream: the three draws happen in forward (q, p) and loss
+        draws = iter([_dev(g["eps_q"]), _dev(g["eps_p"]), _dev(g["eps_ml"])])
+        orig = torch.randn
+        torch.randn = lambda *a, **k: next(draws)
+        try:
+            o = model.forward(x, m, mp, "train")
+            _, tl = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], m, mp, 1400, beta=0.9, alpha=alpha,
+                               beta_annealing=(tag == "kl1.0"))
+        finally:
+            torch.randn = orig
+        for n, t in zip(names, o):
+            _close(t.reshape(g["fwd." + n].shape), torch.from_numpy(g["fwd." + n]), 2e-5, n)
+        ref = float(g[f"loss.{tag}"])
+        assert abs(tl.item() - ref) <= 1e-4 * abs(ref), (tag, tl.item(), ref)
+        tl.backward()
+        _grad_check(model, g, tag)
+    with torch.no_grad():
+        r = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], m, mp, 7, llh_eval=True, stage="evaluate")
+    for got, key in zip(r[1:], ("eval_loss", "eval_re", "eval_re_imp")):
+        assert abs(float(got.detach() if torch.is_tensor(got) else got) - float(g[key])) <= 1e-4 * abs(float(g[key])), key
+
+
+@pytest.mark.parametrize("d", [14, 40])
+def test_vanilla_eddi_against_reference(ed, d):
+    g = load_golden(f"eddi_van_d{d}.npz")
+    model = _load(g, ed.vanilla_EDDI)
+    x, m = _dev(g["x"]), _dev(g["mask"]).float()
+    orig = torch.randn
+    torch.randn = lambda *a, **k: _dev(g["eps_q"])
+    try:
+        o = model.forward(x, m)
+    finally:
+        torch.randn = orig
+    for n, t in zip(["mean", "logvar", "x_mean", "x_logvar"], o):
+        _close(t.reshape(g["fwd." + n].shape), torch.from_numpy(g["fwd." + n]), 2e-5, n)
+    r = model.loss(x, o[2], o[3], o[0], o[1], 3, m, beta=0.8, llh_eval=True)
+    for got, key in zip(r[1:], ("loss", "re", "re_imp")):
+        assert abs(float(got.detach() if torch.is_tensor(got) else got) - float(g[key])) <= 1e-4 * abs(float(g[key])), key
+    r[1].backward()
+    _grad_check(model, g, "v")
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_adam_trajectory(ed, kind):
+    g = load_golden(f"eddi_traj_{kind}_d14.npz")
+    model = _load(g, ed.Reg_EDDI, "kl_reg", prefix="param0.") if kind == "reg" else _load(g, ed.vanilla_EDDI,
+                                                                                          prefix="param0.")
+    model.flatten_parameters()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, m = _dev(g["x"]), _dev(g["mask"])
+    orig = torch.randn
+    for s in range(len(g["losses"])):
+        draws = iter([_dev(e) for e in g["eps"][s]])
+        torch.randn = lambda *a, **k: next(draws)
+        try:
+            if kind == "reg":
+                mp = _dev(g["mask_p"][s])
+                o = model.forward(x, m, mp, stage="train")
+                _, tl = model.loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], m, mp, s + 1, alpha=0.5)
+            else:
+                mf = m.float()
+                o = model.forward(x, mf)
+                _, tl = model.loss(x, o[2], o[3], o[0], o[1], s + 1, mf)
+        finally:
+            torch.randn = orig
+        opt.zero_grad()
+        tl.backward()
+        opt.step()
+        assert abs(tl.item() - g["losses"][s]) <= 1e-4 * abs(g["losses"][s]), (s, tl.item(), g["losses"][s])
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("param5."):
+            _close(sd[k[7:]], torch.from_numpy(v), 5e-5, k)

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_misc.hip", "vpc_reward.hip", "vpc_gemm.hip", "vpc_nm.hip"]
+SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_misc.hip", "vpc_reward.hip", "vpc_gemm.hip", "vpc_nm.hip", "vpc_eddi.hip"]
 HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h"]
 LIB = os.path.join(HERE, "libvpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

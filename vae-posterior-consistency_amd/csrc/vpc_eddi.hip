@@ -1,0 +1,249 @@
+// Point-net ("PNP") encoder front-end of Reg_EDDI / vanilla_EDDI (reference src/models/VAE.py:719-733, 903-917):
+//     h[b][j] = relu( W [x_bj, x_bj * E_j, t_j] + c )   (Linear(2+K -> K) on a [B*d, 2+K] tensor in the reference)
+//     agg[b]  = sum_j mask[b][j] * h[b][j]              -> [B][K], the input of pnp_encoder2 (K -> 100 -> 50 -> 2L)
+// The layer is linear in x_bj before the ReLU, so it folds per feature:  pre[b][j] = x_bj * A_j + C_j  with
+//     A_j = w_x + W_E E_j,   C_j = w_t t_j + c          (W = [w_x | W_E | w_t], [K][2+K])
+// and nothing of size B*d*(2+K) is ever materialised: HBM traffic is x, mask (B*d) in and agg (B*K) out.
+// Backward: dA_j = sum_b g[b][j] x_bj, dC_j = sum_b g[b][j] with g = mask * 1[pre > 0] * dagg[b]; per-lane register
+// accumulators over a grid-stride loop of rows, per-workgroup partials, fixed-order reduction (deterministic), then
+// the chain rule back to (E, t, W, c) in one small workgroup.
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "../../include/vpc.h"
+
+namespace vpc {
+
+constexpr int EDDI_MAX_K = 32;
+
+// AC[0][k][j] = A_j[k], AC[1][k][j] = C_j[k]   (k-major: a lane that owns feature j reads consecutive banks)
+__global__ void eddi_fold_kernel(const float* __restrict__ E, const float* __restrict__ tb, const float* __restrict__ Wp,
+                                 const float* __restrict__ cp, float* __restrict__ AC, int d, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d * K) return;
+    const int k = i / d, j = i % d;
+    const float* w = Wp + (long)k * (2 + K);
+    float a = w[0];
+    for (int e = 0; e < K; ++e) a += w[1 + e] * E[(long)j * K + e];
+    AC[(long)k * d + j] = a;
+    AC[(long)(K + k) * d + j] = w[1 + K] * tb[j] + cp[k];
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void eddi_front_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                             const float* __restrict__ AC, float* __restrict__ agg,
+                                                             int B, int d, int K) {
+    extern __shared__ float lds[];  // [2][K][d]
+    for (int i = threadIdx.x; i < 2 * K * d; i += blockDim.x) lds[i] = AC[i];
+    __syncthreads();
+    const float* sA = lds;
+    const float* sC = lds + K * d;
+    const int lane = threadIdx.x & 63;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int b = gwave; b < B; b += nwaves) {
+        float xv[T], mv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < d;
+            xv[t] = ok ? x[(long)b * d + j] : 0.f;
+            mv[t] = (ok && m[(long)b * d + j]) ? 1.f : 0.f;
+        }
+        float out = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = lane + 64 * t;
+                if (j < d) v += mv[t] * fmaxf(xv[t] * sA[k * d + j] + sC[k * d + j], 0.f);
+            }
+            const float s = wave_sum_dpp(v);
+            if (lane == k) out = s;
+        }
+        if (lane < K) agg[(long)b * K + lane] = out;
+    }
+}
+
+template <int T, int KP>
+__global__ __launch_bounds__(256) void eddi_front_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                             const float* __restrict__ AC,
+                                                             const float* __restrict__ dagg, float* __restrict__ part,
+                                                             int B, int d, int K) {
+    extern __shared__ float lds[];  // [2][K][d], reused for the cross-wave combine ([4][2][K][d] needs 4x: see host)
+    for (int i = threadIdx.x; i < 2 * K * d; i += blockDim.x) lds[i] = AC[i];
+    __syncthreads();
+    const float* sA = lds;
+    const float* sC = lds + K * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    float dA[KP][T], dC[KP][T];
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+#pragma unroll
+        for (int t = 0; t < T; ++t) dA[k][t] = dC[k][t] = 0.f;
+    for (int b = gwave; b < B; b += nwaves) {
+        float xv[T], mv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < d;
+            xv[t] = ok ? x[(long)b * d + j] : 0.f;
+            mv[t] = (ok && m[(long)b * d + j]) ? 1.f : 0.f;
+        }
+        const float dg_lane = lane < K ? dagg[(long)b * K + lane] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (k < K) {  // wave-uniform; no `break`: the loop must unroll fully to keep dA / dC in registers
+                const float dg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dg_lane), k));
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int j = lane + 64 * t;
+                    if (j < d) {
+                        const float pre = xv[t] * sA[k * d + j] + sC[k * d + j];
+                        const float g = pre > 0.f ? mv[t] * dg : 0.f;
+                        dA[k][t] += g * xv[t];
+                        dC[k][t] += g;
+                    }
+                }
+            }
+        }
+    }
+    // ---- combine the 4 waves in wave order through LDS (stage: [4][2][K][d])
+    __syncthreads();
+    float* st = lds + 2 * K * d;  // the host sizes the LDS for 2*K*d (images) + 4*2*K*d (stage)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            if (k < K && j < d) {
+                st[((wave * 2 + 0) * K + k) * d + j] = dA[k][t];
+                st[((wave * 2 + 1) * K + k) * d + j] = dC[k][t];
+            }
+        }
+    }
+    __syncthreads();
+    const int n = 2 * K * d;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        part[(long)blockIdx.x * n + i] = (st[i] + st[n + i]) + (st[2 * n + i] + st[3 * n + i]);
+}
+
+// dAC[i] = sum over the workgroup partials (fixed order)
+__global__ void eddi_reduce_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ dAC) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += part[(long)(g + u) * n + i];
+    }
+    for (; g < G; ++g) acc[0] += part[(long)g * n + i];
+    dAC[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// chain rule from (dA, dC) [K][d] to the four parameter tensors; one workgroup (d * K^2 MACs)
+__global__ __launch_bounds__(256) void eddi_param_bwd_kernel(const float* __restrict__ dAC, const float* __restrict__ E,
+                                                             const float* __restrict__ tb, const float* __restrict__ Wp,
+                                                             float* __restrict__ gE, float* __restrict__ gtb,
+                                                             float* __restrict__ gWp, float* __restrict__ gcp, int d,
+                                                             int K, int accumulate) {
+    const float* dA = dAC;
+    const float* dC = dAC + (long)K * d;
+    auto put = [&](float* p, float v) { *p = accumulate ? *p + v : v; };
+    // dE[j][e] = sum_k W_E[k][e] dA[k][j];   dt[j] = sum_k w_t[k] dC[k][j]
+    for (int i = threadIdx.x; i < d * K; i += blockDim.x) {
+        const int j = i / K, e = i % K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + e] * dA[(long)k * d + j];
+        put(gE + i, s);
+    }
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + K] * dC[(long)k * d + j];
+        put(gtb + j, s);
+    }
+    // dW[k][0] = sum_j dA[k][j]; dW[k][1+e] = sum_j dA[k][j] E[j][e]; dW[k][1+K] = sum_j dC[k][j] t[j]; dc[k] = sum_j dC
+    for (int i = threadIdx.x; i < K * (2 + K); i += blockDim.x) {
+        const int k = i / (2 + K), c = i % (2 + K);
+        float s = 0.f;
+        if (c == 0) for (int j = 0; j < d; ++j) s += dA[(long)k * d + j];
+        else if (c == 1 + K) for (int j = 0; j < d; ++j) s += dC[(long)k * d + j] * tb[j];
+        else for (int j = 0; j < d; ++j) s += dA[(long)k * d + j] * E[(long)j * K + (c - 1)];
+        put(gWp + i, s);
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s += dC[(long)k * d + j];
+        put(gcp + k, s);
+    }
+}
+
+static int eddi_blocks(long B) {
+    long blocks = (B + 3) / 4;
+    const long cap = 2L * num_cus();
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+extern "C" {
+
+int vpc_eddi_fold(const float* E, const float* tb, const float* Wp, const float* cp, float* AC, int d, int K,
+                  void* stream) {
+    if (!E || !tb || !Wp || !cp || !AC) return VPC_ERR_ARG;
+    if (d <= 0 || d > 128 || K <= 0 || K > EDDI_MAX_K) return VPC_ERR_SHAPE;
+    hipLaunchKernelGGL(eddi_fold_kernel, dim3((d * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, E, tb, Wp, cp, AC, d,
+                       K);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+int vpc_eddi_front_fwd(const float* x, const uint8_t* mask, const float* AC, float* agg, long B, int d, int K,
+                       void* stream) {
+    if (!x || !mask || !AC || !agg || B <= 0 || B > 0x7fffff00L) return VPC_ERR_ARG;
+    if (d <= 0 || d > 128 || K <= 0 || K > EDDI_MAX_K) return VPC_ERR_SHAPE;
+    const size_t lds = 2 * (size_t)K * d * sizeof(float);
+    const int blocks = eddi_blocks(B) * 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 64) hipLaunchKernelGGL((eddi_front_fwd_kernel<1>), dim3(blocks), dim3(256), lds, st, x, mask, AC, agg, (int)B, d, K);
+    else hipLaunchKernelGGL((eddi_front_fwd_kernel<2>), dim3(blocks), dim3(256), lds, st, x, mask, AC, agg, (int)B, d, K);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+long vpc_eddi_front_scratch(long B, int d, int K) {  // floats: per-workgroup partials + reduced (dA | dC)
+    if (B <= 0 || d <= 0 || K <= 0) return 0;
+    return (long)(eddi_blocks(B) + 1) * 2 * K * d;
+}
+
+int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const float* AC, const float* dagg, const float* E,
+                       const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE, float* gtb,
+                       float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream) {
+    if (!x || !mask || !AC || !dagg || !E || !tb || !Wp || !scratch || !gE || !gtb || !gWp || !gcp || B <= 0 ||
+        B > 0x7fffff00L)
+        return VPC_ERR_ARG;
+    if (d <= 0 || d > 128 || K <= 0 || K > EDDI_MAX_K) return VPC_ERR_SHAPE;
+    if (scratch_floats < vpc_eddi_front_scratch(B, d, K)) return VPC_ERR_ARG;
+    const int G = eddi_blocks(B), n = 2 * K * d;
+    const size_t lds = (size_t)(2 + 8) * K * d * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = scratch;
+    float* dAC = scratch + (long)G * n;
+#define VPC_EDDI_BWD(T, KP)                                                                                          \
+    do {                                                                                                             \
+        if (!lds_attr_done(reinterpret_cast<const void*>(&eddi_front_bwd_kernel<T, KP>), lds)) return VPC_ERR_HIP;   \
+        hipLaunchKernelGGL((eddi_front_bwd_kernel<T, KP>), dim3(G), dim3(256), lds, st, x, mask, AC, dagg, part, (int)B, \
+                           d, K);                                                                                    \
+    } while (0)
+    if (d <= 64) { if (K <= 16) VPC_EDDI_BWD(1, 16); else VPC_EDDI_BWD(1, 32); }
+    else { if (K <= 16) VPC_EDDI_BWD(2, 16); else VPC_EDDI_BWD(2, 32); }
+#undef VPC_EDDI_BWD
+    if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(eddi_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, G, n, dAC);
+    hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3(1), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp, gcp, d, K,
+                       accumulate);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+"""PNP / EDDI encoder family: drop-in classes for the reference's
+
+    Reg_EDDI       src/models/VAE.py:670-853
+    vanilla_EDDI   src/models/VAE.py:856-992
+
+Same constructor arguments, `encoder` / `decoder` / `forward` / `loss` signatures, return order and state_dict keys
+(type_pars1, type_bias1, prior_mean, prior_std, pnp_encoder1.0, pnp_encoder2.{0,2,4}, seq_decoder.{0,2,4}).  Decoder
+and loss are those of Reg_VAE / vanilla_VAE (same HIP kernels, inherited); the encoder is the point-net front-end
+(csrc/vpc_eddi.hip: folded per-feature affine + ReLU + mask-weighted sum, nothing of size B*d*(2+K) materialised)
+followed by pnp_encoder2 as three fp32 MFMA GEMMs (csrc/vpc_gemm.hip).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from ._lib import check, lib, ptr, require_cuda, stream_ptr
+from .models import MAX_EPOCH, Reg_VAE, vanilla_VAE
+from .notmiwae import ACT_NONE, ACT_RELU, linear_dgrad, linear_fwd, linear_wgrad, nm_sample, nm_sample_bwd
+from .ops import as_mask_u8
+
+H1, H2 = 100, 50  # VAE.py:694-698 hard-codes 100 / 50
+
+
+def eddi_fold(E, tb, Wp, cp, AC, d, K):
+    check(lib().vpc_eddi_fold(ptr(E), ptr(tb), ptr(Wp), ptr(cp), ptr(AC), d, K, stream_ptr()), "vpc_eddi_fold")
+
+
+def eddi_front_fwd(x, mask_u8, AC, agg, B, d, K):
+    check(lib().vpc_eddi_front_fwd(ptr(x), ptr(mask_u8), ptr(AC), ptr(agg), B, d, K, stream_ptr()),
+          "vpc_eddi_front_fwd")
+
+
+def eddi_front_bwd(x, mask_u8, AC, dagg, E, tb, Wp, gE, gtb, gWp, gcp, B, d, K, accumulate=False):
+    need = int(lib().vpc_eddi_front_scratch(B, d, K))
+    sc = torch.empty(need, device=x.device)
+    check(lib().vpc_eddi_front_bwd(ptr(x), ptr(mask_u8), ptr(AC), ptr(dagg), ptr(E), ptr(tb), ptr(Wp), ptr(sc), need,
+                                   ptr(gE), ptr(gtb), ptr(gWp), ptr(gcp), int(accumulate), B, d, K, stream_ptr()),
+          "vpc_eddi_front_bwd")
+
+
+class EDDIEncoderFn(torch.autograd.Function):
+    """(x, mask, eps) -> (z, mean, logvar).  Reference: VAE.py:713-741 / 897-925."""
+
+    @staticmethod
+    def forward(ctx, model, x, mask_u8, eps, W1, b1, W2, b2, W3, b3, E, tb, Wp, cp):
+        require_cuda(x, mask_u8, eps, W1, E)
+        d, Ld, K = model.obs_dim, model.latent_dim, model.emb_dim
+        B, dev = x.shape[0], x.device
+        AC = torch.empty(2, K, d, device=dev)
+        eddi_fold(E, tb, Wp, cp, AC, d, K)
+        agg = torch.empty(B, K, device=dev)
+        eddi_front_fwd(x, mask_u8, AC, agg, B, d, K)
+        h1 = torch.empty(B, H1, device=dev)
+        h2 = torch.empty(B, H2, device=dev)
+        heads = torch.empty(B, 2 * Ld, device=dev)
+        linear_fwd(agg, W1, b1, h1, B, H1, K, ACT_RELU)
+        linear_fwd(h1, W2, b2, h2, B, H2, H1, ACT_RELU)
+        linear_fwd(h2, W3, b3, heads, B, 2 * Ld, H2, ACT_NONE)
+        z = torch.empty(B, Ld, device=dev)
+        nm_sample(heads, eps, z, B, 1, Ld)
+        ctx.model = model
+        ctx.has_eps = eps is not None
+        ctx.save_for_backward(x, mask_u8, AC, agg, h1, h2, heads, eps if eps is not None else torch.empty(0, device=dev),
+                              W1, W2, W3, E, tb, Wp)
+        return z, heads[:, :Ld], heads[:, Ld:]
+
+    @staticmethod
+    def backward(ctx, dz, dmean, dlogvar):
+        model = ctx.model
+        x, mask_u8, AC, agg, h1, h2, heads, eps, W1, W2, W3, E, tb, Wp = ctx.saved_tensors
+        eps = eps if ctx.has_eps else None
+        d, Ld, K = model.obs_dim, model.latent_dim, model.emb_dim
+        B, dev = x.shape[0], x.device
+        gh = torch.cat([dmean, dlogvar], 1).float().contiguous()
+        dht = torch.empty(B, 2 * Ld, device=dev)
+        nm_sample_bwd(dz.float().contiguous(), eps, heads, gh, dht, B, 1, Ld)
+        e = lambda *s: torch.empty(*s, device=dev)
+        gW1, gb1, gW2, gb2, gW3, gb3 = e(H1, K), e(H1), e(H2, H1), e(H2), e(2 * Ld, H2), e(2 * Ld)
+        dh2, dh1, dagg = e(B, H2), e(B, H1), e(B, K)
+        linear_wgrad(dht, h2, gW3, gb3, B, 2 * Ld, H2)
+        linear_dgrad(dht, W3, dh2, B, 2 * Ld, H2, x_out=h2, act_prev=ACT_RELU)
+        linear_wgrad(dh2, h1, gW2, gb2, B, H2, H1)
+        linear_dgrad(dh2, W2, dh1, B, H2, H1, x_out=h1, act_prev=ACT_RELU)
+        linear_wgrad(dh1, agg, gW1, gb1, B, H1, K)
+        linear_dgrad(dh1, W1, dagg, B, H1, K)
+        gE, gtb, gWp, gcp = e(d, K), e(d, 1), e(K, 2 + K), e(K)
+        eddi_front_bwd(x, mask_u8, AC, dagg, E, tb, Wp, gE, gtb, gWp, gcp, B, d, K)
+        return None, None, None, None, gW1, gb1, gW2, gb2, gW3, gb3, gE, gtb, gWp, gcp
+
+
+class _EDDIBase:
+    """Shared construction / parameter plumbing; mixed in BEFORE Reg_VAE / vanilla_VAE, whose decoder(), forward()
+    and loss() (and the kernels behind them) are reused unchanged."""
+
+    def _build(self, obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples, num_estimates):
+        nn.Module.__init__(self)
+        if obs_dim > 128 or latent_dim > 15 or K > 32:
+            raise L.VpcError("the gfx950 EDDI kernels support obs_dim <= 128, latent_dim <= 15 and K (emb_dim) <= 32")
+        self.obs_dim, self.hid_dim, self.emb_dim, self.latent_dim = obs_dim, hid_dim, K, latent_dim
+        self.K = K
+        self.batch_size = training_parameters["batch_size"]
+        self.training_parameters = training_parameters
+        self.experiment_type = experiment_type
+        self.num_samples, self.num_estimates = num_samples, num_estimates
+        # containers in the reference's construction order (same seed -> same initial weights), VAE.py:687-709
+        self.pnp_encoder1 = nn.Sequential(nn.Linear(2 + K, K), nn.ReLU())
+        self.pnp_encoder2 = nn.Sequential(nn.Linear(K, H1), nn.ReLU(), nn.Linear(H1, H2), nn.ReLU(),
+                                          nn.Linear(H2, 2 * latent_dim))
+        self.seq_decoder = nn.Sequential(nn.Linear(latent_dim, H2), nn.ReLU(), nn.Linear(H2, H1), nn.ReLU(),
+                                         nn.Linear(H1, obs_dim), nn.Sigmoid())
+        xlv = torch.log(torch.square(torch.Tensor([0.1 * np.sqrt(2)])))
+        self.register_buffer("x_logvar", xlv, persistent=False)
+        self._x_logvar_value = float(xlv.item())
+        self.type_pars1 = nn.Parameter(torch.zeros(obs_dim, K), requires_grad=True)
+        nn.init.xavier_uniform_(self.type_pars1)
+        self.type_bias1 = nn.Parameter(torch.zeros(obs_dim, 1), requires_grad=True)
+        nn.init.xavier_uniform_(self.type_bias1)
+        self.prior_mean = nn.Parameter(torch.zeros(latent_dim), requires_grad=False)
+        self.prior_std = nn.Parameter(torch.ones(latent_dim), requires_grad=False)
+        self.max_epoch = MAX_EPOCH
+        self._layout = None
+        self._img = None
+        self._img_version = None
+        self._part = {}
+
+    # flat order: [pnp_encoder2 (6) | seq_decoder (6) | type_pars1, type_bias1, pnp_encoder1 (2)] - the decoder sits at
+    # indices 6..11 as in the VAE classes, which is what DecoderFn's gradient split assumes
+    def trainable(self):
+        out = []
+        for name in ("pnp_encoder2.0", "pnp_encoder2.2", "pnp_encoder2.4", "seq_decoder.0", "seq_decoder.2",
+                     "seq_decoder.4"):
+            mod = self.get_submodule(name)
+            out += [mod.weight, mod.bias]
+        return out + [self.type_pars1, self.type_bias1, self.pnp_encoder1[0].weight, self.pnp_encoder1[0].bias]
+
+    def _versions(self):
+        return tuple(p._version for p in self.trainable()) + (self.seq_decoder[0].weight.data_ptr(),)
+
+    def _images(self):
+        """Only the DECODER half of the packed image is used (the encoder is the front-end + GEMM trunk)."""
+        lay = self._lay()
+        flat = self.flatten_parameters()
+        L.require_cuda(flat)
+        v = self._versions()
+        if self._img is None or self._img.device != flat.device:
+            self._img = torch.from_numpy(lay.img_template).to(flat.device)
+            self._img_version = None
+        if self._img_version != v:
+            pidx, _ = lay.device_tables(flat.device)
+            n_trunk = sum(p.numel() for p in self.trainable()[:6])
+            n_dec = lay.n_params - lay.n_enc
+            ops.pack_weights(flat[n_trunk:n_trunk + n_dec], pidx[lay.n_enc:], self._img)
+            self._img_version = v
+        return self._img
+
+    def decoder(self, z_int):
+        """VAE.py:743-747: the Reg_VAE decoder kernels on this class's seq_decoder (trainable()[6:12])."""
+        L.require_cuda(z_int)
+        self._lay()
+        self._images()
+        return ops.DecoderFn.apply(self, z_int, *self.trainable()[6:12]), self.x_logvar
+
+    def encoder(self, x, mask, sample=True):
+        """VAE.py:713-741 / 897-925: returns (z, mean, logvar)."""
+        L.require_cuda(x)
+        if mask.shape[0] == 0:  # VAE.py:717-718
+            return torch.empty(0, 10), torch.empty(0, 10), torch.empty(0, 10)
+        self._images()
+        xf = ops._f32c(x.reshape(-1, self.obs_dim))
+        m = as_mask_u8(mask.reshape(-1, self.obs_dim).to(x.device))
+        eps = torch.randn(xf.shape[0], self.latent_dim, device=xf.device) if sample else None
+        t = self.trainable()
+        return EDDIEncoderFn.apply(self, xf, m, eps, *t[:6], *t[12:])
+
+
+class Reg_EDDI(_EDDIBase, Reg_VAE):
+    """Reference: src/models/VAE.py:670-853."""
+
+    def __init__(self, obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, reg_type, num_samples=1,
+                 num_estimates=1):
+        self._build(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples, num_estimates)
+        self.reg_type = reg_type
+
+    def forward(self, data, mask, mask_p, stage="train"):
+        return Reg_VAE.forward(self, data, mask, mask_p, stage)
+
+    def loss(self, x, x_recon_p, x_logvar_p, mean_p, logvar_p, x_recon_q, x_logvar_q, mean_q, logvar_q, mask, mask_p,
+             epoch, vae_elbo=False, llh_eval=False, MI=False, beta_annealing=False, beta=1.0, alpha=0.5, stage="train",
+             alpha_annealing=False):
+        """VAE.py:749-813: Reg_VAE.loss with this class's defaults (alpha = 0.5)."""
+        return Reg_VAE.loss(self, x, x_recon_p, x_logvar_p, mean_p, logvar_p, x_recon_q, x_logvar_q, mean_q, logvar_q,
+                            mask, mask_p, epoch, vae_elbo, llh_eval, MI, beta_annealing, beta, alpha, stage,
+                            alpha_annealing)
+
+
+class vanilla_EDDI(_EDDIBase, vanilla_VAE):
+    """Reference: src/models/VAE.py:856-992."""
+
+    def __init__(self, obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples=1,
+                 num_estimates=1):
+        self._build(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples, num_estimates)
+
+    def loss(self, x, x_recon_q, x_logvar_q, mean_q, logvar_q, epoch, mask, vae_elbo=False, llh_eval=False, MI=False,
+             beta_annealing=False, beta=1.0, alpha=0.5, stage="train"):
+        """VAE.py:933-964: vanilla_VAE.loss, except that RE_q_imputed is computed in EVERY stage (:938-939)."""
+        return vanilla_VAE.loss(self, x, x_recon_q, x_logvar_q, mean_q, logvar_q, epoch, mask, vae_elbo, llh_eval, MI,
+                                beta_annealing, beta, alpha, True, "evaluate")
