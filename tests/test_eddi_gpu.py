@@ -146,3 +146,27 @@ def test_adam_trajectory(ed, kind):
     for k, v in g.items():
         if k.startswith("param5."):
             _close(sd[k[7:]], torch.from_numpy(v), 5e-5, k)
+
+
+def test_harness_train_and_eval_eddi(ed, tmp_path, monkeypatch):
+    """train() (train.py:13-133) and eval_vae (evaluate.py:136-297) for the EDDI families, incl. the 'with_drop'
+    keep-mask of create_missing_uci_drop_eddi (utils.py:42-45); checkpoints keep the reference's names."""
+    import os
+    import vpc_amd
+    from torch.utils.data import DataLoader, TensorDataset
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    x = torch.rand(96, 14)
+    m = torch.rand(96, 14) < 0.7
+    loader = DataLoader(TensorDataset(x, m), batch_size=32, shuffle=False)
+    tp = {"batch_size": 32, "patience": 1}
+    for vae_type in ("reg_EDDI1", "vanilla_EDDI1_with_drop"):
+        torch.manual_seed(1)
+        model = vpc_amd.train((loader, None), 30, 14, 500, 10, 1, 10, "toy", tp, "exp", vae_type, 1, 1, max_epochs=3,
+                              alpha=0.5, p_missingness=30, reg_type="kl_reg", verbose=False)
+        ck = vpc_amd.checkpoint_path("exp", "toy", vae_type, 30, alpha=0.5, p_missingness=30, reg_type="kl_reg")
+        assert os.path.exists(ck) and os.path.basename(os.path.dirname(ck)) == vae_type.split("1")[0]
+        res = vpc_amd.eval_vae([(loader, "test")], 30, 14, 500, 10, 2, 10, "toy", tp, "exp", vae_type, 3, 1, 1,
+                               alpha=0.5, p_missingness=30, reg_type="kl_reg")
+        r = res["test"]
+        assert all(torch.isfinite(v) for v in r.values()) and 0.05 < float(r["rmse"]) < 0.6

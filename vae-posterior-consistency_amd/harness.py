@@ -22,6 +22,7 @@ from . import ops
 from .fused import FusedTrainer
 from .models import Reg_VAE, Reg_VAE_mask, vanilla_VAE, vanilla_VAE_mask
 from .notmiwae import NMTrainer, REG_notMIWAE_v2, notMIWAE_myversion
+from .eddi import Reg_EDDI, vanilla_EDDI
 
 _seed_counter = [0]
 
@@ -55,14 +56,21 @@ def model_loader(stage, obs_dim, hid_dim, K, latent_dim, missing_rate, data_type
                  num_samples, num_estimates, experiment_type, reg_type, vae_type="vae", alpha=1.0, p_missingness=30,
                  beta=0.5, beta_annealing=True, alpha_annealing=True, not_miwae_type="changed"):
     """Same positional signature and substring dispatch as loaders.py:13-246 for the in-scope families."""
-    if "flow" in vae_type or "EDDI" in vae_type or ("MIWAE" in vae_type and "notMIWAE" not in vae_type):
-        raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* / *_notMIWAE* are on the "
-                                  "accelerated path")
+    if "flow" in vae_type or ("MIWAE" in vae_type and "notMIWAE" not in vae_type) or \
+            ("EDDI" in vae_type and data_type == "mnist"):
+        raise NotImplementedError(f"vae_type {vae_type!r}: only reg_vae* / vanilla_vae* / *_notMIWAE* / *_EDDI* (UCI) "
+                                  "are on the accelerated path")
     augm = "mask_augm" in vae_type  # loaders.py:47, 143
     if "reg_notMIWAE" in vae_type:  # loaders.py:89-103
         model = REG_notMIWAE_v2(obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates)
     elif "vanilla_notMIWAE" in vae_type:  # loaders.py:219-233
         model = notMIWAE_myversion(obs_dim, hid_dim, K, latent_dim, training_parameters, num_samples, num_estimates)
+    elif "reg_EDDI" in vae_type:  # loaders.py:104-131 (UCI branch)
+        model = Reg_EDDI(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, reg_type, num_samples,
+                         num_estimates)
+    elif "vanilla_EDDI" in vae_type:  # loaders.py:196-218
+        model = vanilla_EDDI(obs_dim, hid_dim, K, latent_dim, training_parameters, experiment_type, num_samples,
+                             num_estimates)
     elif "reg_vae" in vae_type:
         model = (Reg_VAE_mask if augm else Reg_VAE)(obs_dim, hid_dim, K, latent_dim, training_parameters,
                                                     experiment_type, reg_type, num_samples, num_estimates)
@@ -95,6 +103,8 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
     nm = "notMIWAE" in vae_type
     loader = data_loader_train if nm else data_loader_train[0]  # train.py:22-25
     is_reg = "reg" in vae_type
+    if "EDDI" in vae_type:
+        fused = False  # the EDDI classes train on the API path (front-end + GEMM trunk + fused decoder / loss kernels)
     if fused:
         trainer = (NMTrainer if nm else FusedTrainer)(model, lr=0.001, seed=seed)
     else:
@@ -120,8 +130,12 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
                 _, train_loss = model.loss(data_sample, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], mask, mask_p,
                                            i + 1, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
                                            alpha_annealing=alpha_annealing, stage=stage)
-            else:  # train.py:58, 95-101
-                mask_drop = torch.ones(data_sample.shape, device=device)
+            else:  # train.py:50-51, 58, 95-101
+                if "with_drop" in vae_type:  # create_missing_uci_drop_eddi (utils.py:42-45): keep ~ Bern(1 - min(U, .99))
+                    keep_p = 1.0 - torch.rand(data_sample.shape, device=device).clamp_(max=0.99)
+                    mask_drop = (torch.rand(data_sample.shape, device=device) < keep_p).float()
+                else:
+                    mask_drop = torch.ones(data_sample.shape, device=device)
                 o = model.forward(data_sample, mask * mask_drop)
                 _, train_loss = model.loss(data_sample, o[2], o[3], o[0], o[1], i + 1, mask * mask_drop,
                                            beta_annealing=beta_annealing, beta=beta, stage=stage)
@@ -175,7 +189,7 @@ def eval_vae(list_loaders, missing_rate, obs_dim, hid_dim, K, M, latent_dim, dat
                                  p_missingness=p_missingness)
         model.to(device)
         opt_epoch = max_epochs
-        is_reg = "reg_vae" in vae_type
+        is_reg = "reg_vae" in vae_type or "reg_EDDI" in vae_type
         for loader, loader_stage in list_loaders:
             recon, res, res_negll, res_negll_imp = [], [], [], []
             for _ in range(M):
