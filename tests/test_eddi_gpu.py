@@ -170,3 +170,52 @@ def test_harness_train_and_eval_eddi(ed, tmp_path, monkeypatch):
                                alpha=0.5, p_missingness=30, reg_type="kl_reg")
         r = res["test"]
         assert all(torch.isfinite(v) for v in r.values()) and 0.05 < float(r["rmse"]) < 0.6
+
+
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_fused_trainer_trajectory(ed, kind):
+    """EDDITrainer (front-end + stacked trunk GEMMs + the VAE step's fused decoder kernel + flat Adam) reproduces the
+    reference's 5-step trajectory; afterwards the API path sees the updated weights (packed image in step)."""
+    g = load_golden(f"eddi_traj_{kind}_d14.npz")
+    model = _load(g, ed.Reg_EDDI, "kl_reg", prefix="param0.") if kind == "reg" else _load(g, ed.vanilla_EDDI,
+                                                                                          prefix="param0.")
+    tr = ed.EDDITrainer(model, lr=1e-3)
+    x, m = _dev(g["x"]), _dev(g["mask"])
+    for s in range(len(g["losses"])):
+        eps = _dev(g["eps"][s])
+        if kind == "reg":
+            tr.step(x, m, mask_p=_dev(g["mask_p"][s]), eps_q=eps[0], eps_p=eps[1], epoch=s + 1, alpha=0.5)
+        else:
+            tr.step(x, m, eps_q=eps[0], epoch=s + 1)
+        assert abs(tr.loss_value() - g["losses"][s]) <= 1e-4 * abs(g["losses"][s]), (s, tr.loss_value())
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("param5."):
+            _close(sd[k[7:]], torch.from_numpy(v), 5e-5, k)
+    # the decoder image used by the API path follows the in-place Adam updates
+    with torch.no_grad():
+        z = torch.zeros(4, int(g["L"]), device="cuda")
+        xhat, _ = model.decoder(z)
+        ref = torch.sigmoid(torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(torch.relu(
+            torch.nn.functional.linear(z, sd["seq_decoder.0.weight"], sd["seq_decoder.0.bias"])),
+            sd["seq_decoder.2.weight"], sd["seq_decoder.2.bias"])), sd["seq_decoder.4.weight"], sd["seq_decoder.4.bias"]))
+    _close(xhat, ref, 2e-5, "decoder after fused steps")
+
+
+def test_fused_trainer_device_draws(ed):
+    torch.manual_seed(2)
+    B, d, K = 256, 100, 20
+    x = torch.rand(B, d, device="cuda")
+    m = torch.rand(B, d, device="cuda") < 0.7
+    finals = []
+    for rep in range(2):
+        torch.manual_seed(3)
+        model = ed.Reg_EDDI(d, 500, K, 10, {"batch_size": B, "patience": 1}, "exp", "kl_reg").cuda()
+        tr = ed.EDDITrainer(model, seed=9)
+        losses = []
+        for s in range(8):
+            tr.step(x, m, epoch=s + 1, alpha=0.5, p_missingness=30)
+            losses.append(tr.loss_value())
+        assert losses[-1] < losses[0]
+        finals.append((losses, model._flat.clone()))
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])

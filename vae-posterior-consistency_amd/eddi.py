@@ -209,3 +209,164 @@ class vanilla_EDDI(_EDDIBase, vanilla_VAE):
         """VAE.py:933-964: vanilla_VAE.loss, except that RE_q_imputed is computed in EVERY stage (:938-939)."""
         return vanilla_VAE.loss(self, x, x_recon_q, x_logvar_q, mean_q, logvar_q, epoch, mask, vae_elbo, llh_eval, MI,
                                 beta_annealing, beta, alpha, True, "evaluate")
+
+
+# ------------------------------------------------------------------------------------------------ fused step
+LP = 16  # row pitch of the padded latent workspaces of the fused decoder kernel
+
+
+class EDDITrainer:
+    """The EDDI training step (train.py:28-117 for 'reg_EDDI*' / 'vanilla_EDDI*') as a fixed launch sequence without
+    host synchronisation: mask_p + eps draws -> fold -> front-end (both passes) -> pnp_encoder2 GEMMs on the stacked
+    passes -> the SAME fused decoder + loss + decoder-backward kernel as the VAE step (nothing of size B x d is
+    materialised) -> trunk backward GEMMs -> front-end backward -> [one all-reduce of [grads | loss terms]] -> flat
+    Adam + decoder image re-pack."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+        if not isinstance(model, _EDDIBase):
+            raise TypeError("EDDITrainer supports Reg_EDDI and vanilla_EDDI")
+        from .fused import FusedTrainer
+        self.model = model
+        self.vanilla = isinstance(model, vanilla_VAE)
+        self.coefficients = lambda *a: FusedTrainer.coefficients(self, *a)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.seed, self.rng_offset, self.step_count = seed, 0, 0
+        self.pg, self.world_size = process_group, world_size
+        self.lay = model._lay()
+        flat = model.flatten_parameters()
+        L.require_cuda(flat)
+        self.dev = flat.device
+        n = flat.numel()
+        self.bucket = torch.zeros(n + 9, device=self.dev)
+        self.grad, self.out9 = self.bucket[:n], self.bucket[n:]
+        self.exp_avg = torch.zeros(n, device=self.dev)
+        self.exp_avg_sq = torch.zeros(n, device=self.dev)
+        self.accum = torch.zeros(1, device=self.dev)
+        ncu = L.num_cus()
+        self.partD = torch.empty(ncu * self.lay.dec_part, device=self.dev)
+        self.loss_part = torch.empty(ncu, 8, dtype=torch.float64, device=self.dev)
+        self.pidx, self.gidx = self.lay.device_tables(self.dev)
+        # gradient views in flat order: trunk (6) | decoder (6) | front-end (4)
+        self.g, off = [], 0
+        for p in model.trainable():
+            v = self.grad[off:off + p.numel()].view_as(p)
+            p.grad = v
+            self.g.append(v)
+            off += p.numel()
+        self.n_trunk = sum(p.numel() for p in model.trainable()[:6])
+        self.n_dec = self.lay.n_params - self.lay.n_enc
+        self._B = None
+
+    def _ws(self, B):
+        if self._B == B:
+            return
+        m, dev = self.model, self.dev
+        d, Ld, K = m.obs_dim, m.latent_dim, m.emb_dim
+        P = 1 if self.vanilla else 2
+        e = lambda *s: torch.empty(*s, device=dev)
+        self.AC = e(2, K, d)
+        self.agg, self.h1, self.h2, self.heads = e(P * B, K), e(P * B, H1), e(P * B, H2), e(P * B, 2 * Ld)
+        self.lat = torch.zeros(P, 2, B, LP, device=dev)    # [pass][mean | logvar][B][16]
+        self.dlat = torch.zeros(P, 2, B, LP, device=dev)
+        self.dheads, self.dh2, self.dh1, self.dagg = e(P * B, 2 * Ld), e(P * B, H2), e(P * B, H1), e(P * B, K)
+        self.eps_buf = e(3, B, LP)
+        self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
+        self._B = B
+
+    def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=0.5, beta=1.0,
+             beta_annealing=False, p_missingness=30, global_batch=None):
+        m, lay = self.model, self.lay
+        d, Ld, K = m.obs_dim, m.latent_dim, m.emb_dim
+        x = ops._f32c(x.reshape(-1, d))
+        L.require_cuda(x)
+        mask = as_mask_u8(mask.reshape(-1, d))
+        B = x.shape[0]
+        self._ws(B)
+        Bg = global_batch if global_batch is not None else B * self.world_size
+        co = self.coefficients(epoch, alpha, beta, beta_annealing)
+        two = not self.vanilla
+        P = 2 if two else 1
+        t = m.trainable()
+        W1, b1, W2, b2, W3, b3 = t[:6]
+        E, tb, Wp, cp = t[12:]
+        dec_img = m._dec_img()
+        # ---- draws
+        need_ml = two and co["wml"] != 0.0
+        eps_view = self.eps_buf[: (3 if need_ml else 2 if two else 1)]
+        inject = eps_q is not None
+        if two and mask_p is None:
+            off_m = self.rng_offset
+            self.rng_offset += (B * d + 3) // 4
+            ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
+                          self.rng_offset)
+            self.rng_offset += (eps_view.numel() + 3) // 4
+            mask_p = self.mask_p_buf
+        else:
+            if two:
+                mask_p = as_mask_u8(mask_p.reshape(-1, d))
+            if not inject:
+                ops.fill_normal(eps_view, self.seed, self.rng_offset)
+                self.rng_offset += (eps_view.numel() + 3) // 4
+        if eps_q is not None:
+            self.eps_buf[0, :, :Ld].copy_(eps_q)
+        if two and eps_p is not None:
+            self.eps_buf[1, :, :Ld].copy_(eps_p)
+        if need_ml and eps_ml is not None:
+            self.eps_buf[2, :, :Ld].copy_(eps_ml)
+        masks = [mask, mask_p] if two else [mask]
+        # ---- encoder: front-end per pass, trunk on the stacked passes
+        eddi_fold(E, tb, Wp, cp, self.AC, d, K)
+        for p_, mk in enumerate(masks):
+            eddi_front_fwd(x, mk, self.AC, self.agg[p_ * B:(p_ + 1) * B], B, d, K)
+        R = P * B
+        linear_fwd(self.agg, W1, b1, self.h1, R, H1, K, ACT_RELU)
+        linear_fwd(self.h1, W2, b2, self.h2, R, H2, H1, ACT_RELU)
+        linear_fwd(self.h2, W3, b3, self.heads, R, 2 * Ld, H2, ACT_NONE)
+        self.lat[..., :Ld].copy_(self.heads.view(P, B, 2, Ld).permute(0, 2, 1, 3))
+        mean = [self.lat[p_, 0] for p_ in range(P)]
+        logvar = [self.lat[p_, 1] for p_ in range(P)]
+        dmean = [self.dlat[p_, 0] for p_ in range(P)]
+        dlogvar = [self.dlat[p_, 1] for p_ in range(P)]
+        epss = [self.eps_buf[p_] for p_ in range(P)]
+        eml = self.eps_buf[2] if need_ml else None
+        # ---- fused decoder + loss + decoder backward (the VAE step's kernel)
+        maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * P
+        nbD = ops.decoder_fused(x, dec_img, masks, maskB, co["cA"], co["cE"], mean, logvar, epss, eml, co["bq"],
+                                co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, dmean, dlogvar, self.partD,
+                                self.loss_part, d, Ld, LP)
+        gdec = self.grad[self.n_trunk:self.n_trunk + self.n_dec]
+        ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], gdec)
+        cA1 = co["cA"][1] if two else 0.0
+        ops.loss_finalize(self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B,
+                          Bg, d, self.out9, self.accum if self.world_size == 1 else None)
+        # ---- encoder backward
+        self.dheads.view(P, B, 2, Ld).copy_(self.dlat[..., :Ld].permute(0, 2, 1, 3))
+        g = self.g
+        linear_wgrad(self.dheads, self.h2, g[4], g[5], R, 2 * Ld, H2)
+        linear_dgrad(self.dheads, W3, self.dh2, R, 2 * Ld, H2, x_out=self.h2, act_prev=ACT_RELU)
+        linear_wgrad(self.dh2, self.h1, g[2], g[3], R, H2, H1)
+        linear_dgrad(self.dh2, W2, self.dh1, R, H2, H1, x_out=self.h1, act_prev=ACT_RELU)
+        linear_wgrad(self.dh1, self.agg, g[0], g[1], R, H1, K)
+        linear_dgrad(self.dh1, W1, self.dagg, R, H1, K)
+        for p_, mk in enumerate(masks):
+            eddi_front_bwd(x, mk, self.AC, self.dagg[p_ * B:(p_ + 1) * B], E, tb, Wp, g[12], g[13], g[14], g[15], B, d,
+                           K, accumulate=p_ > 0)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+            self.accum += self.out9[0]
+        self.step_count += 1
+        ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
+                      self.betas[1], self.eps)
+        # keep the packed decoder image in step with the parameters (the version check would re-pack it anyway)
+        ops.pack_weights(m._flat[self.n_trunk:self.n_trunk + self.n_dec], self.pidx[lay.n_enc:], m._img)
+        m._img_version = m._versions()
+
+    def loss_value(self) -> float:
+        return float(self.out9[0].item())
+
+    def epoch_total(self, reset=True) -> float:
+        v = float(self.accum.item())
+        if reset:
+            self.accum.zero_()
+        return v

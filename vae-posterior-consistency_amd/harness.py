@@ -22,7 +22,7 @@ from . import ops
 from .fused import FusedTrainer
 from .models import Reg_VAE, Reg_VAE_mask, vanilla_VAE, vanilla_VAE_mask
 from .notmiwae import NMTrainer, REG_notMIWAE_v2, notMIWAE_myversion
-from .eddi import Reg_EDDI, vanilla_EDDI
+from .eddi import EDDITrainer, Reg_EDDI, vanilla_EDDI
 
 _seed_counter = [0]
 
@@ -103,10 +103,11 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
     nm = "notMIWAE" in vae_type
     loader = data_loader_train if nm else data_loader_train[0]  # train.py:22-25
     is_reg = "reg" in vae_type
-    if "EDDI" in vae_type:
-        fused = False  # the EDDI classes train on the API path (front-end + GEMM trunk + fused decoder / loss kernels)
+    eddi = "EDDI" in vae_type
+    if eddi and "with_drop" in vae_type:
+        fused = False  # the per-element keep-mask of the with_drop variants is applied on the API path
     if fused:
-        trainer = (NMTrainer if nm else FusedTrainer)(model, lr=0.001, seed=seed)
+        trainer = (NMTrainer if nm else EDDITrainer if eddi else FusedTrainer)(model, lr=0.001, seed=seed)
     else:
         model.flatten_parameters()
         optimizer = torch.optim.Adam(model.parameters(), lr=0.001)  # train.py:21
