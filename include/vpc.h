@@ -141,6 +141,16 @@ int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, 
                     float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
                     long long* state, long long rng_inc, void* stream);
 
+/* vpc_reduce_step + vpc_adam_step in ONE launch (single process, eager): Adam is elementwise, so the thread that
+ * finishes gradient i updates parameter i (and its packed-image entry) on the spot.  Same result as the two
+ * calls in sequence; `step` >= 1 is the optimiser step count of THIS update. */
+int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
+                         int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                         const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
+                         float bp, float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
+                         float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                         float eps, long step, const int* pack_idx, float* img, void* stream);
+
 /* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
 
 /* mask_out = mask_in AND (U < keep_prob): create_missing_uci(shape, rate) * mask with keep_prob = 1 - rate/100

@@ -48,6 +48,8 @@ _PROTOS = {
                           P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
     "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, C.c_longlong, P],
+    "vpc_reduce_step_adam": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, P, P, F, F, F,
+                             F, L_, P, P, P],
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
     "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P],

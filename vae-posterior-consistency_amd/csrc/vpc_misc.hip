@@ -48,9 +48,26 @@ __global__ void pack_kernel(const float* __restrict__ flat, const int* __restric
 // out[i] = scale * sum_b part[b * stride + idx[i]].  A 256-thread block handles 32 parameters x 8 block
 // groups (thread (pi, bg) sums blocks bg, bg+8, ...), then the 8 group sums are added in a fixed order:
 // bitwise reproducible, and 8x more loads in flight than one thread per parameter.
+// optional optimiser update fused into the gradient reduction (Adam is elementwise: the thread that finishes
+// gradient i owns parameter i); param == nullptr disables it
+struct AdamFuse {
+    float* param; float* m; float* v; const int* pack_idx; float* img;
+    float lr, b1, b2, eps, bc1, bc2_sqrt;
+};
+__device__ __forceinline__ void adam_apply(const AdamFuse& A, int i, float g) {
+#pragma clang fp contract(off)  // one rounding sequence wherever this is inlined (stand-alone Adam == fused Adam, bitwise)
+    const float mi = A.b1 * A.m[i] + (1.f - A.b1) * g;
+    const float vi = A.b2 * A.v[i] + (1.f - A.b2) * g * g;
+    A.m[i] = mi;
+    A.v[i] = vi;
+    const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+    const float pnew = A.param[i] - (A.lr / A.bc1) * (mi / denom);
+    A.param[i] = pnew;
+    if (A.pack_idx) A.img[A.pack_idx[i]] = pnew;
+}
 __device__ __forceinline__ void reduce_body(const float* __restrict__ part, int nblocks, long stride,
                                             const int* __restrict__ idx, float* __restrict__ out, int n, float scale,
-                                            int blk, float (*sh)[32]) {
+                                            int blk, float (*sh)[32], const AdamFuse* adam = nullptr, int base = 0) {
     const int pi = threadIdx.x & 31, bg = threadIdx.x >> 5;
     const int i = blk * 32 + pi;
     float s0 = 0.f, s1 = 0.f;
@@ -70,6 +87,7 @@ __device__ __forceinline__ void reduce_body(const float* __restrict__ part, int 
 #pragma unroll
         for (int k = 1; k < 8; ++k) t += sh[k][pi];
         out[i] = scale * t;
+        if (adam && adam->param) adam_apply(*adam, base + i, scale * t);
     }
 }
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nblocks, long stride,
@@ -91,15 +109,7 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
         bc1 = (float)(1.0 - pow((double)b1, t));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
     }
-    const float g = grad[i];
-    const float mi = b1 * m[i] + (1.f - b1) * g;
-    const float vi = b2 * v[i] + (1.f - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    const float pnew = param[i] - (lr / bc1) * (mi / denom);
-    param[i] = pnew;
-    if (pack_idx) img[pack_idx[i]] = pnew;
+    adam_apply(AdamFuse{param, m, v, pack_idx, img, lr, b1, b2, eps, bc1, bc2_sqrt}, i, grad[i]);
 }
 
 // loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums;
@@ -145,14 +155,15 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restric
                                                           int n_enc, int n, const double* __restrict__ lp, int nbL,
                                                           LossCoef k, float* __restrict__ out9,
                                                           float* __restrict__ accum, long long* __restrict__ state,
-                                                          long long rng_inc) {
+                                                          long long rng_inc, AdamFuse adam) {
     __shared__ float shf[8][32];
     __shared__ double shd[32][LOSS_TERMS];
     __shared__ double s[LOSS_TERMS];
     const int gE = (n_enc + 31) / 32, gD = (n - n_enc + 31) / 32;
     const int b = blockIdx.x;
-    if (b < gE) reduce_body(partE, nbE, strideE, idx, grad, n_enc, 1.f, b, shf);
-    else if (b < gE + gD) reduce_body(partD, nbD, strideD, idx + n_enc, grad + n_enc, n - n_enc, 1.f, b - gE, shf);
+    if (b < gE) reduce_body(partE, nbE, strideE, idx, grad, n_enc, 1.f, b, shf, &adam, 0);
+    else if (b < gE + gD)
+        reduce_body(partD, nbD, strideD, idx + n_enc, grad + n_enc, n - n_enc, 1.f, b - gE, shf, &adam, n_enc);
     else {
         finalize_body(lp, nbL, k, out9, accum, shd, s);
         if (state && threadIdx.x == 0) {  // device-side step / RNG counters for graph replay
@@ -519,7 +530,29 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
     const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
     hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                        enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
-                       loss_blocks, k, out9, accum, state, rng_inc);
+                       loss_blocks, k, out9, accum, state, rng_inc, AdamFuse{});
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_stride,
+                                    const float* dec_partials, int dec_blocks, long dec_stride, const int* grad_idx,
+                                    float* grad_out, int n_enc, int n, const double* loss_partials, int loss_blocks,
+                                    float cA0, float cE0, float cA1, float bq, float bp, float cr, float wml,
+                                    long B_local, long B_global, int d, float* out9, float* accum, float* params,
+                                    float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                    long step, const int* pack_idx, float* img, void* stream) {
+    if (!enc_partials || !dec_partials || !grad_idx || !grad_out || !loss_partials || !out9) return VPC_ERR_ARG;
+    if (enc_blocks <= 0 || dec_blocks <= 0 || loss_blocks <= 0 || n_enc <= 0 || n <= n_enc) return VPC_ERR_ARG;
+    if (!params || !exp_avg || !exp_avg_sq || step < 1 || (pack_idx == nullptr) != (img == nullptr)) return VPC_ERR_ARG;
+    const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
+                     1.0 / (double)B_global};
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2)};
+    const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
+    hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                       enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
+                       loss_blocks, k, out9, accum, (long long*)nullptr, 0LL, A);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

@@ -63,6 +63,7 @@ class FusedTrainer:
         self.timers = None  # bench.py sets this to {} to collect per-kernel HIP event pairs
         self.timer_every = 8  # ... on every 8th step only: an event pair costs ~5 us of GPU idle time per kernel
         self._timer_tick = 0
+        self.timer_names = None  # restrict the event pairs to these launches (None = all)
         # make trainable tensors' .grad views of the flat gradient, so state is inspectable like torch's
         off = 0
         for p in model.trainable():
@@ -88,7 +89,8 @@ class FusedTrainer:
 
     def _timed(self, name, fn, *args):
         """Run one launch; with timers enabled bracket it with events on the launch stream."""
-        if self.timers is None or self._timer_tick % self.timer_every:
+        if self.timers is None or self._timer_tick % self.timer_every or \
+                (self.timer_names is not None and name not in self.timer_names):
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -171,19 +173,29 @@ class FusedTrainer:
                           self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
                           self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm)
-        # ---- flat gradient + loss terms: one launch
+        # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
-        ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part, self.gidx, self.grad, lay.n_enc,
-                        self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg,
-                        d, self.out9, self.accum if self.world_size == 1 else None, _state,
-                        self.rng_offset - rng0 if _state is not None else 0)
+        if update and self.world_size == 1 and _state is None:
+            self.step_count += 1
+            ops.reduce_step_adam(self.partE, nbE, lay.enc_part, self.partD, nbD,
+                        lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
+                        cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
+                        self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                        self.step_count, self.pidx, img)
+            return
+        ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part,
+                    self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"],
+                    co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9,
+                    self.accum if self.world_size == 1 else None, _state,
+                    self.rng_offset - rng0 if _state is not None else 0)
         if self.world_size > 1:
             self._allreduce()
             self.accum += self.out9[0]
         if update:
             self.step_count += 1
-            ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.pidx, img, None if _state is None else _state[0:1])
+            ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
+                        self.lr, self.betas[0], self.betas[1], self.eps, self.pidx, img,
+                        None if _state is None else _state[0:1])
 
     # ------------------------------------------------------------------ HIP-graph replay of the step
     def step_graph(self, x, mask, *, epoch=1, alpha=1.0, beta=1.0, beta_annealing=False, p_missingness=30):

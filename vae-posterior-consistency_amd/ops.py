@@ -114,6 +114,15 @@ def reduce_step(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc,
                                 ptr(out9), ptr(accum), ptr(state), int(rng_inc), stream_ptr()), "vpc_reduce_step")
 
 
+def reduce_step_adam(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq,
+                     bp, cr, wml, B_local, B_global, d, out9, accum, params, m, v, lr, beta1, beta2, eps, step, pack_idx,
+                     img):
+    check(lib().vpc_reduce_step_adam(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(grad),
+                                     n_enc, grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local,
+                                     B_global, d, ptr(out9), ptr(accum), ptr(params), ptr(m), ptr(v), lr, beta1, beta2,
+                                     eps, int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_reduce_step_adam")
+
+
 def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
     check(lib().vpc_draw_mask(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), int(seed), int(offset),
                               stream_ptr()), "vpc_draw_mask")
