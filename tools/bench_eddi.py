@@ -4,6 +4,7 @@ torch.optim.Adam on one MI355X, the front-end kernels timed separately, the CPU 
     python tools/bench_eddi.py [--batch 64] [--d 128] [--k 20] [--vanilla] [--no-cpu]
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -59,11 +60,14 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()  # a gen-2 collection inside the loop stalls the host for tens of ms (profiles/r01_notes.md)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         tl = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    gc.enable()
     # front-end kernels alone (HBM-bound: x fp32 + mask u8 in, agg out)
     mu8 = m.view(torch.uint8)
     AC = torch.empty(2, K, d, device="cuda")

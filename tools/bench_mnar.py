@@ -8,6 +8,7 @@ FLOP model (algorithmic, fp32 MAC = 2 FLOP): forward per encoder row 2*(d*128 + 
 2*(L*128 + 128*128 + 128*2d); backward = 2x forward (dgrad + wgrad) minus the first-layer dgrad of the encoder.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -56,11 +57,14 @@ def main():
     torch.cuda.synchronize()
     if a.timers:
         tr.timers = {}
+    gc.collect()
+    gc.disable()  # a gen-2 collection inside the loop stalls the host for tens of ms (profiles/r01_notes.md)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         stepfn(x, m, alpha=0.5, p_missingness=50)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    gc.enable()
     passes = 1 if a.vanilla else 2
     fl = flops_per_step(B, K, d, L, passes)
     out = {"metric": "MNAR training samples/sec (REG_notMIWAE_v2 step, K=20)" if not a.vanilla else
