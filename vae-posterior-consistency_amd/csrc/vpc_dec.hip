@@ -107,8 +107,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     // (the fused mode always works on the padded workspaces, the API modes on dense [B][L] tensors)
     constexpr bool PAD = (MODE == MODE_FUSED);
     auto ld_lat = [&](const float* base, long r, bool rok) -> f32x4 {
-        if (PAD) return ld_tile<true>(base, r, 16, 4 * q, 16, rok);
-        return ld_tile<false>(base, r, a.L, 4 * q, a.L, rok);
+        if (PAD) return ld_tile_o<true>(base, r, 16, 4 * q, 16, rok);
+        return ld_tile_o<false>(base, r, a.L, 4 * q, a.L, rok);
     };
     auto st_lat = [&](float* base, long r, bool rok, f32x4 v) {
         if (PAD) {
@@ -153,12 +153,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                 }
                 const f32x4 mu = ld_lat(a.mean[p], row[nb], ok[nb]);
                 const f32x4 lv = ld_lat(a.logvar[p], row[nb], ok[nb]);
-                f32x4 e = zero4();
-                if (a.eps[p]) {
-                    e = ld_lat(a.eps[p], row[nb], ok[nb]);
+                // optional arrays are aliased to a valid one and and-ed away (no branch: the loads of this tile can
+                // then be issued together instead of one exposed latency per CFG join)
+                f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row[nb], ok[nb]), opaque_mask(a.eps[p] != nullptr));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
-                }
+                for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float sig = __expf(0.5f * lv[j]);
@@ -170,11 +169,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     // every KL term and seed below is exactly 0, so no per-lane branch is needed (only the
                     // ml_reg log-likelihood has a non-zero value at 0 and is masked explicitly).
                     const bool two = a.npass == 2;
-                    f32x4 mo = zero4(), lo = zero4();
-                    if (two) {
-                        mo = ld_lat(a.mean[1 - p], row[nb], ok[nb]);
-                        lo = ld_lat(a.logvar[1 - p], row[nb], ok[nb]);
-                    }
+                    const uint32_t has_o = opaque_mask(two);
+                    const f32x4 mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row[nb], ok[nb]), has_o);
+                    const f32x4 lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row[nb], ok[nb]), has_o);
                     const float b0 = (p == 0) ? a.bq : a.bp;
                     const float sgn = (p == 0) ? 1.f : -1.f;  // d KL(q||p) / d mu_q = -d / d mu_p
                     const float crr = two ? a.cr : 0.f;
@@ -258,8 +255,41 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                 f32x4 xv_cur[NB];
                 uint32_t ua_cur[NB], ub_cur[NB];
                 const bool hasB = (MODE == MODE_FUSED) && a.mB[p] != nullptr;
+                // Fused + vector mode: per-lane row addresses are formed ONCE per pass (rows / columns out of range are
+                // clamped to a valid address and their values multiplied / and-ed away).  No select sits on a loaded
+                // value and the second mask is always read (aliased to the first when absent): hipcc turns
+                // `ok ? load : 0` and `if (hasB) load` into exec-masked branches whose joins carry s_waitcnt vmcnt(0),
+                // i.e. two to three fully exposed HBM latencies per output tile (seen in the ISA of the r01 build).
+                constexpr bool FAST = (MODE == MODE_FUSED) && VEC;
+                const float* xl[NB];
+                const uint32_t* mal[NB];
+                const uint32_t* mbl[NB];
+                const float hasBf = hasB ? 1.f : 0.f;
+                if (FAST) {
+                    const int cq = (4 * q + 3 < a.d) ? 4 * q : 0;
+                    const uint8_t* mbp = hasB ? a.mB[p] : a.mA[p];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const long ro = (ok[nb] ? row[nb] : 0) * a.d + cq;
+                        xl[nb] = a.x + ro;
+                        mal[nb] = reinterpret_cast<const uint32_t*>(a.mA[p] + ro);
+                        mbl[nb] = reinterpret_cast<const uint32_t*>(mbp + ro);
+                    }
+                }
                 auto fetch = [&](int mt, f32x4 (&xv)[NB], uint32_t (&ua)[NB], uint32_t (&ub)[NB]) {
                     const int f0 = 16 * mt + 4 * q;
+                    if (FAST) {
+                        const bool colok = f0 + 3 < a.d;
+                        const int fo = colok ? 16 * mt : 0;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const uint32_t vm = opaque_mask(ok[nb] && colok);
+                            xv[nb] = and4(*reinterpret_cast<const f32x4*>(xl[nb] + fo), vm);
+                            ua[nb] = mal[nb][fo >> 2] & vm;
+                            ub[nb] = mbl[nb][fo >> 2] & vm;
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         ua[nb] = 0u; ub[nb] = 0u;
@@ -301,7 +331,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             dxh = pre_cur[nb] * a.inv_B;
                         } else if (MODE == MODE_FUSED) {
                             const f32x4 mA = mask_to_f32(ua_cur[nb]);
-                            const f32x4 mE = hasB ? mA * (1.f - mask_to_f32(ub_cur[nb])) : zero4();
+                            const f32x4 mE = FAST ? mA * (1.f - mask_to_f32(ub_cur[nb])) * hasBf
+                                                  : (hasB ? mA * (1.f - mask_to_f32(ub_cur[nb])) : zero4());
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float diff = xh[j] - xv_cur[nb][j];

@@ -167,6 +167,38 @@ __device__ __forceinline__ f32x4 ld_tile(const float* base, long row, int ld, in
     }
     return v;
 }
+// Opaque all-ones / zero mask: hipcc rewrites both `ok ? loaded : 0` and `loaded & (ok ? ~0 : 0)` into an exec-masked
+// branch around the load, and the join of that branch carries `s_waitcnt vmcnt(0)`, so every such load exposes a
+// full HBM latency (r01 ISA of the decoder kernel: 2-3 per output tile, ~10 in the latent prologue of each pass).
+// The and-with-opaque-mask form keeps the load unconditional.  It costs a few VGPRs; the encoder kernels, which sit
+// at their register limit, keep the select form below (with it enc_bwd spills: 120 -> 136 us).
+__device__ __forceinline__ uint32_t opaque_mask(bool ok) {
+    uint32_t m = ok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));
+    return m;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 and4(f32x4 v, uint32_t m) {
+    const u32x4 b = __builtin_bit_cast(u32x4, v) & m;
+    return __builtin_bit_cast(f32x4, b);
+}
+// ld_tile with the opaque mask (decoder kernel)
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld_tile_o(const float* base, long row, int ld, int f0, int nvalid, bool row_ok) {
+    const long off = row * ld + f0;
+    f32x4 v;
+    if (VEC) {
+        const bool ok = row_ok && f0 + 3 < nvalid;
+        v = and4(*reinterpret_cast<const f32x4*>(base + (ok ? off : 0)), opaque_mask(ok));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row_ok && f0 + j < nvalid;
+            v[j] = __uint_as_float(__float_as_uint(base[ok ? off + j : 0]) & opaque_mask(ok));
+        }
+    }
+    return v;
+}
 template <bool VEC>
 __device__ __forceinline__ void st_tile(float* base, long row, int ld, int f0, int nvalid, bool row_ok, f32x4 v) {
     float* p = base + row * ld + f0;
