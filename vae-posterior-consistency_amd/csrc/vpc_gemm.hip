@@ -39,24 +39,33 @@ struct LinArgs {
     int vecA, vecB, vecC, vecX;    // 16-byte path usable for the operand / output / aux
 };
 
-__device__ __forceinline__ float act_fwd(float v, int act, bool second) {
-    switch (act) {
-        // hardware exp / rcp (v_exp_f32, v_rcp_f32): |abs err| < 2e-7 on outputs in (-1, 1); the IEEE expm1f / expf +
-        // divide expansions cost ~40 VALU instructions per element, as much as the MFMAs of a K = 128 layer
-        case ACT_ELU: return v > 0.f ? v : __expf(v) - 1.f;
-        case ACT_SIGMOID_HARDTANH:
-            return second ? fminf(fmaxf(v, -10.f), 0.f) : __builtin_amdgcn_rcpf(1.f + __expf(-v));
-        case ACT_RELU: return fmaxf(v, 0.f);
-        default: return v;
-    }
+// The activation code is a kernel ARGUMENT; it is dispatched ONCE per tile (act_dispatch) into code specialised on it,
+// never per element: a per-element `switch` costs a branch forest per value (the first build of the epilogue spent as
+// long in it as in the MFMAs of a K = 128 layer).
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v, bool second) {
+    // hardware exp / rcp (v_exp_f32, v_rcp_f32): |abs err| < 2e-7 on outputs in (-1, 1)
+    if (ACT == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
+    if (ACT == ACT_SIGMOID_HARDTANH) return second ? fminf(fmaxf(v, -10.f), 0.f) : __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+    return v;
 }
 // derivative of the activation expressed through its OUTPUT y
-__device__ __forceinline__ float act_grad(float y, int act, bool second) {
+template <int ACT>
+__device__ __forceinline__ float act_grad(float y, bool second) {
+    if (ACT == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (ACT == ACT_SIGMOID_HARDTANH) return second ? ((y > -10.f && y < 0.f) ? 1.f : 0.f) : y * (1.f - y);
+    if (ACT == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+template <int V> struct ActC { static constexpr int value = V; };
+template <typename F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
     switch (act) {
-        case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
-        case ACT_SIGMOID_HARDTANH: return second ? ((y > -10.f && y < 0.f) ? 1.f : 0.f) : y * (1.f - y);
-        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        default: return 1.f;
+        case ACT_ELU: f(ActC<ACT_ELU>{}); break;
+        case ACT_SIGMOID_HARDTANH: f(ActC<ACT_SIGMOID_HARDTANH>{}); break;
+        case ACT_RELU: f(ActC<ACT_RELU>{}); break;
+        default: f(ActC<ACT_NONE>{}); break;
     }
 }
 
@@ -67,42 +76,49 @@ constexpr int IT = 2;             // 16 x 16 MFMA tiles per wave along the A-ope
 // batches, 1 (32 batch rows per workgroup, 4x the workgroups: at the reference's batch 128 x K 20 a 128-row tiling
 // would occupy 40 of the 256 CUs)
 
-// ---- global -> registers: a ROWS x COLS tile (ROWS * COLS = 8192), zero-filled outside [rlim) x [clim)
+// ---- global -> registers: a ROWS x COLS tile (ROWS * COLS / 4 / 512 float4 per thread), zero-filled outside
+// [rlim) x [clim).  Interior tiles with 16-byte access take a path without any per-load predicate; the gate (dY *= act'(Y),
+// head layers on the API path) is applied in a second, activation-specialised sweep.
+template <int COLS>
+__device__ __forceinline__ f32x4 gload_one(int i, bool interior, const float* __restrict__ base, long ld, int r0, int c0,
+                                           int rlim, int clim, int vec) {
+    constexpr int C4 = COLS / 4;
+    const int idx = threadIdx.x + LIN_THREADS * i;
+    const int row = r0 + idx / C4, col = c0 + 4 * (idx % C4);
+    const float* p = base + (long)row * ld + col;
+    if (interior) return *reinterpret_cast<const f32x4*>(p);
+    f32x4 v = zero4();
+    if (row < rlim && col < clim) {
+        if (vec && col + 3 < clim) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < clim) v[e] = p[e];
+        }
+    }
+    return v;
+}
 template <int COLS, int NLD>
 __device__ __forceinline__ void gload(f32x4 (&r)[NLD], const float* __restrict__ base, long ld, int r0, int c0,
                                       int rlim, int clim, int vec, const float* __restrict__ yg, long ldy, int gate,
                                       int gate_split) {
     constexpr int C4 = COLS / 4;
+    constexpr int ROWS = NLD * LIN_THREADS / C4;
+    const bool interior = vec && r0 + ROWS <= rlim && c0 + COLS <= clim;  // workgroup-uniform
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = threadIdx.x + LIN_THREADS * i;
-        const int row = r0 + idx / C4, col = c0 + 4 * (idx % C4);
-        f32x4 v = zero4();
-        if (row < rlim && col < clim) {
-            const float* p = base + (long)row * ld + col;
-            if (vec && col + 3 < clim) {
-                v = *reinterpret_cast<const f32x4*>(p);
-            } else {
+    for (int i = 0; i < NLD; ++i) r[i] = gload_one<COLS>(i, interior, base, ld, r0, c0, rlim, clim, vec);
+    if (!yg) return;
+    act_dispatch(gate, [&](auto actc) {
+        constexpr int G = decltype(actc)::value;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < clim) v[e] = p[e];
-            }
-            if (yg) {
-                const float* py = yg + (long)row * ldy + col;
-                f32x4 y = zero4();
-                if (vec && col + 3 < clim) {
-                    y = *reinterpret_cast<const f32x4*>(py);
-                } else {
+        for (int i = 0; i < NLD; ++i) {
+            const f32x4 y = gload_one<COLS>(i, interior, yg, ldy, r0, c0, rlim, clim, vec);
+            const int col = c0 + 4 * ((threadIdx.x + LIN_THREADS * i) % C4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < clim) y[e] = py[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_grad(y[e], gate, col + e >= gate_split);
-            }
+            for (int e = 0; e < 4; ++e) r[i][e] *= act_grad<G>(y[e], col + e >= gate_split);
         }
-        r[i] = v;
-    }
+    });
 }
 // ---- registers -> swizzled LDS tile
 template <int COLS, int NLD>
@@ -247,47 +263,51 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
             a.bias_part[(long)blockIdx.x * a.N + i0 + threadIdx.x] = bsum;
         return;
     }
+    act_dispatch(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int f = i0 + 16 * IT * wr + 16 * it + 4 * q;  // first of 4 consecutive output features
-        if (f >= ilim) continue;
-        f32x4 bv = zero4();
-        if (MODE == LIN_FWD && a.bias) {
+        for (int it = 0; it < IT; ++it) {
+            const int f = i0 + 16 * IT * wr + 16 * it + 4 * q;  // first of 4 consecutive output features
+            if (f >= ilim) continue;
+            const bool full4 = f + 3 < ilim;
+            f32x4 bv = zero4();
+            if (MODE == LIN_FWD && a.bias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (f + e < ilim) bv[e] = a.bias[f + e];
-        }
+                for (int e = 0; e < 4; ++e)
+                    if (f + e < ilim) bv[e] = a.bias[f + e];
+            }
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const int row = j0 + 16 * JT * wc + 16 * jt + c;
-            if (row >= jlim) continue;
-            f32x4 v = acc[it][jt];
-            if (MODE == LIN_FWD) {
+            for (int jt = 0; jt < JT; ++jt) {
+                const int row = j0 + 16 * JT * wc + 16 * jt + c;
+                if (row >= jlim) continue;
+                f32x4 v = acc[it][jt];
+                if (MODE == LIN_FWD) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e] + bv[e], a.act, f + e >= a.split);
-            } else if (a.aux) {
-                const float* px = a.aux + (long)row * a.ldaux + f;
-                f32x4 xo = zero4();
-                if (a.vecX && f + 3 < ilim) {
-                    xo = *reinterpret_cast<const f32x4*>(px);
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd<ACT>(v[e] + bv[e], f + e >= a.split);
+                } else if (a.aux) {
+                    const float* px = a.aux + (long)row * a.ldaux + f;
+                    f32x4 xo = zero4();
+                    if (a.vecX && full4) {
+                        xo = *reinterpret_cast<const f32x4*>(px);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (f + e < ilim) xo[e] = px[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_grad<ACT>(xo[e], f + e >= a.split);
+                }
+                float* pc = a.C + (long)row * a.ldc + f;
+                if (a.vecC && full4) {
+                    *reinterpret_cast<f32x4*>(pc) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (f + e < ilim) xo[e] = px[e];
+                        if (f + e < ilim) pc[e] = v[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_grad(xo[e], a.act, f + e >= a.split);
-            }
-            float* pc = a.C + (long)row * a.ldc + f;
-            if (a.vecC && f + 3 < ilim) {
-                *reinterpret_cast<f32x4*>(pc) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (f + e < ilim) pc[e] = v[e];
             }
         }
-    }
+    });
 }
 
 // sum the per-split partial blocks in split order (deterministic); accumulate != 0 adds to dW / db
