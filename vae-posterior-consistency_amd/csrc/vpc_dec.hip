@@ -379,13 +379,23 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fb[H1T];
 #pragma unroll
                             for (int nt = 0; nt < H1T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
+                            // Ownership (out tile w + 4i < DT) is decided ONCE per slice, never per MFMA: a predicate
+                            // on the runtime wave index around each MFMA puts every one of them into its own basic
+                            // block (s_cmp + s_cbranch per MFMA - the r01 ISA - which doubled the time of this phase).
+                            constexpr bool ALL6 = 4 * (I6 - 1) + 3 < DT;  // every wave owns all of its I6 tiles
+                            if (ALL6 || w + 4 * (I6 - 1) < DT) {
 #pragma unroll
-                            for (int nt = 0; nt < H1T; ++nt)
+                                for (int nt = 0; nt < H1T; ++nt)
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
+                                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                                    for (int i = 0; i < I6; ++i)
-                                        if (w + 4 * i < DT) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[nt][j], acc6[i][nt]);
+                                        for (int i = 0; i < I6; ++i) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[nt][j], acc6[i][nt]);
+                            } else if (w < DT) {  // only the first tile (I6 == 2) or a narrow model (DT < 4)
+#pragma unroll
+                                for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) acc6[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc6[0][nt]);
+                            }
                         }
                     }
                     // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
@@ -422,13 +432,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fb[H2T];
 #pragma unroll
                             for (int nt = 0; nt < H2T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
+                            if (w + 4 < H1T) {  // waves 0..2 own two out tiles, wave 3 one (decided once per slice)
 #pragma unroll
-                            for (int nt = 0; nt < H2T; ++nt)
+                                for (int nt = 0; nt < H2T; ++nt)
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
-                                    if (w + 4 < H1T) acc5[1][nt] = VPC_MFMA(fa[1][j], fb[nt][j], acc5[1][nt]);
-                                }
+                                    for (int j = 0; j < 4; ++j) {
+                                        acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
+                                        acc5[1][nt] = VPC_MFMA(fa[1][j], fb[nt][j], acc5[1][nt]);
+                                    }
+                            } else {
+#pragma unroll
+                                for (int nt = 0; nt < H2T; ++nt)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
+                            }
                         }
                     }
                     // ---------------- dg1 = relu'(g1) * (W5~^T dg2)
