@@ -376,25 +376,27 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fa[I6];
 #pragma unroll
                             for (int i = 0; i < I6; ++i) fa[i] = stage_frag<CH>(stA, (w + 4 * i) % DT, s, cc, qq);
-                            f32x4 fb[H1T];
-#pragma unroll
-                            for (int nt = 0; nt < H1T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
-                            // Ownership (out tile w + 4i < DT) is decided ONCE per slice, never per MFMA: a predicate
-                            // on the runtime wave index around each MFMA puts every one of them into its own basic
-                            // block (s_cmp + s_cbranch per MFMA - the r01 ISA - which doubled the time of this phase).
+                            // B fragments are double-buffered by hand: hipcc sinks every LDS read to just before its
+                            // first use (read -> s_waitcnt lgkmcnt(0) -> 8 MFMAs, one exposed LDS latency per 8 MFMAs in
+                            // the r01 ISA); the sched_barrier pins the read of fragment nt+1 above the MFMAs of nt
                             constexpr bool ALL6 = 4 * (I6 - 1) + 3 < DT;  // every wave owns all of its I6 tiles
-                            if (ALL6 || w + 4 * (I6 - 1) < DT) {
+                            const bool own_all = ALL6 || w + 4 * (I6 - 1) < DT, own_0 = w < DT;
+                            f32x4 fb_cur = stage_frag<CH>(stB, 0, s, cc, qq);
 #pragma unroll
-                                for (int nt = 0; nt < H1T; ++nt)
+                            for (int nt = 0; nt < H1T; ++nt) {
+                                const f32x4 fb_nxt = stage_frag<CH>(stB, nt + 1 < H1T ? nt + 1 : nt, s, cc, qq);
+                                __builtin_amdgcn_sched_barrier(0);
+                                // ownership (out tile w + 4i < DT) is decided per fragment, never per MFMA
+                                if (own_all) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                                        for (int i = 0; i < I6; ++i) acc6[i][nt] = VPC_MFMA(fa[i][j], fb[nt][j], acc6[i][nt]);
-                            } else if (w < DT) {  // only the first tile (I6 == 2) or a narrow model (DT < 4)
+                                        for (int i = 0; i < I6; ++i) acc6[i][nt] = VPC_MFMA(fa[i][j], fb_cur[j], acc6[i][nt]);
+                                } else if (own_0) {
 #pragma unroll
-                                for (int nt = 0; nt < H1T; ++nt)
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) acc6[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc6[0][nt]);
+                                    for (int j = 0; j < 4; ++j) acc6[0][nt] = VPC_MFMA(fa[0][j], fb_cur[j], acc6[0][nt]);
+                                }
+                                fb_cur = fb_nxt;
                             }
                         }
                     }
@@ -429,22 +431,23 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             f32x4 fa[2];
                             fa[0] = stage_frag<CH>(stA, w, s, cc, qq);
                             fa[1] = stage_frag<CH>(stA, (w + 4) % H1T, s, cc, qq);
-                            f32x4 fb[H2T];
+                            const bool two5 = w + 4 < H1T;  // waves 0..2 own two out tiles, wave 3 one
+                            f32x4 fb_cur = stage_frag<CH>(stB, 0, s, cc, qq);
 #pragma unroll
-                            for (int nt = 0; nt < H2T; ++nt) fb[nt] = stage_frag<CH>(stB, nt, s, cc, qq);
-                            if (w + 4 < H1T) {  // waves 0..2 own two out tiles, wave 3 one (decided once per slice)
-#pragma unroll
-                                for (int nt = 0; nt < H2T; ++nt)
+                            for (int nt = 0; nt < H2T; ++nt) {
+                                const f32x4 fb_nxt = stage_frag<CH>(stB, nt + 1 < H2T ? nt + 1 : nt, s, cc, qq);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (two5) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) {
-                                        acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
-                                        acc5[1][nt] = VPC_MFMA(fa[1][j], fb[nt][j], acc5[1][nt]);
+                                        acc5[0][nt] = VPC_MFMA(fa[0][j], fb_cur[j], acc5[0][nt]);
+                                        acc5[1][nt] = VPC_MFMA(fa[1][j], fb_cur[j], acc5[1][nt]);
                                     }
-                            } else {
+                                } else {
 #pragma unroll
-                                for (int nt = 0; nt < H2T; ++nt)
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) acc5[0][nt] = VPC_MFMA(fa[0][j], fb[nt][j], acc5[0][nt]);
+                                    for (int j = 0; j < 4; ++j) acc5[0][nt] = VPC_MFMA(fa[0][j], fb_cur[j], acc5[0][nt]);
+                                }
+                                fb_cur = fb_nxt;
                             }
                         }
                     }
