@@ -228,11 +228,16 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
                     for (int s = 0; s < WPC; ++s) {
                         const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
+                        // A fragments double-buffered by hand (hipcc sinks each LDS read to its first use: one exposed
+                        // LDS latency per 4 MFMAs); the sched_barrier pins the read of mt+1 above the MFMAs of mt
+                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
 #pragma unroll
                         for (int mt = 0; mt < H2T; ++mt) {
-                            const f32x4 fa = stage_frag<CH>(stA, mt, s, cc, qq);
+                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H2T ? mt + 1 : mt, s, cc, qq);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc2[mt] = VPC_MFMA(fa[j], fb[j], acc2[mt]);
+                            fa = fn;
                         }
                     }
                 }
@@ -245,14 +250,17 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 dh1[mt] = gate4(tile_T<H2T, 128>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
                 // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then the
                 // c == 0 lanes add into this wave's private LDS row (same lane every time -> fixed order)
+                // (DPP adds, no LDS round trips: the __shfl_xor butterfly is 4 ds_bpermute + 4 waits per value, and the
+                // read-modify-write behind it two more - for 28 values per pass that chain cost as many cycles as all
+                // MFMAs of the pass.  ds_add_f32 without return needs no wait; one lane per address -> fixed order.)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = dh1[mt][j];
-                    v += __shfl_xor(v, 1, 64);
-                    v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 4, 64);
-                    v += __shfl_xor(v, 8, 64);
-                    if (c == 0) db1s[w * 128 + 16 * mt + 4 * q + j] += v;
+                    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+                    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+                    v += dpp_mov<0x141>(v);  // row_half_mirror
+                    v += dpp_mov<0x140>(v);  // row_mirror: every lane of the 16-lane row holds the row sum
+                    if (c == 0) atomicAdd(&db1s[w * 128 + 16 * mt + 4 * q + j], v);
                 }
             }
             f32x4 xin[DT];
@@ -273,11 +281,14 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
                     for (int s = 0; s < WPC; ++s) {
                         const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
+                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
 #pragma unroll
                         for (int mt = 0; mt < H1T; ++mt) {
-                            const f32x4 fa = stage_frag<CH>(stA, mt, s, cc, qq);
+                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H1T ? mt + 1 : mt, s, cc, qq);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc1[mt] = VPC_MFMA(fa[j], fb[j], acc1[mt]);
+                            fa = fn;
                         }
                     }
                 }
