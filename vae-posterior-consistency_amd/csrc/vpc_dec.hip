@@ -100,6 +100,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * w;
+    int sb[4];  // per-lane element offsets of the wgrad staging writes (tile 0); tiles add a compile-time constant
+    stage_bases<DEC_CH>(sb, colbase, c, q);
     const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
     constexpr float HL2PI = 0.91893853320467274f;
 
@@ -365,9 +367,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
 #pragma unroll
-                        for (int t = 0; t < DT; ++t) stage_write<CH>(stA, t, dpre[ch][t], colbase, cc, qq);
+                        for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[ch][t], sb);
 #pragma unroll
-                        for (int t = 0; t < H1T; ++t) stage_write<CH>(stB, t, g2[ch][t], colbase, cc, qq);
+                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[ch][t], sb);
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
 #pragma unroll
@@ -420,9 +422,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
 #pragma unroll
-                        for (int t = 0; t < H1T; ++t) stage_write<CH>(stA, t, dg2[ch][t], colbase, cc, qq);
+                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[ch][t], sb);
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write<CH>(stB, t, g1[ch][t], colbase, cc, qq);
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[ch][t], sb);
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
 #pragma unroll
@@ -471,8 +473,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write<CH>(stA, t, dg1[ch][t], colbase, cc, qq);
-                        stage_write<CH>(stB, 0, z[ch][0], colbase, cc, qq);
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[ch][t], sb);
+                        stage_write_b<CH>(stB, 0, z[ch][0], sb);
                         __syncthreads();
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
