@@ -163,6 +163,8 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * (w % WPC);
+    int sb[4];  // per-lane element offsets of the staging writes (tile 0); tiles add a compile-time constant
+    stage_bases<CH>(sb, colbase, c, q);
 
     f32x4 acc1[H1T], acc2[H2T], acc3 = zero4();
 #pragma unroll
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
                 __syncthreads();
                 if (w / WPC == ch) {
-                    stage_write<CH>(stA, 0, dml[0], colbase, cc, qq);
-                    stage_write<CH>(stA, 1, dml[1], colbase, cc, qq);
+                    stage_write_b<CH>(stA, 0, dml[0], sb);
+                    stage_write_b<CH>(stA, 1, dml[1], sb);
 #pragma unroll
-                    for (int t = 0; t < H2T; ++t) stage_write<CH>(stB, t, h2[t], colbase, cc, qq);
+                    for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
                 }
                 __syncthreads();
 #pragma unroll
@@ -219,9 +221,9 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 __syncthreads();
                 if (w / WPC == ch) {
 #pragma unroll
-                    for (int t = 0; t < H2T; ++t) stage_write<CH>(stA, t, dh2[t], colbase, cc, qq);
+                    for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dh2[t], sb);
 #pragma unroll
-                    for (int t = 0; t < H1T; ++t) stage_write<CH>(stB, t, h1[t], colbase, cc, qq);
+                    for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, h1[t], sb);
                 }
                 __syncthreads();
                 if (w < H1T) {
@@ -272,9 +274,9 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 __syncthreads();
                 if (w / WPC == ch) {
 #pragma unroll
-                    for (int t = 0; t < H1T; ++t) stage_write<CH>(stA, t, dh1[t], colbase, cc, qq);
+                    for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
 #pragma unroll
-                    for (int t = 0; t < DT; ++t) stage_write<CH>(stB, t, xin[t], colbase, cc, qq);
+                    for (int t = 0; t < DT; ++t) stage_write_b<CH>(stB, t, xin[t], sb);
                 }
                 __syncthreads();
                 if (w < DT) {
