@@ -207,3 +207,62 @@ def test_two_rank_mnar_trainer_matches_single_process():
     # sharding changes the fp32 summation order of the weight gradients; Adam's m / sqrt(v) turns a 1e-7 relative
     # difference of a tiny gradient into up to lr = 1e-3 per step, so parameters are compared at 3e-5 of their scale
     assert np.max(np.abs(flat1 - flat2)) <= 3e-5 * np.max(np.abs(flat1))
+
+
+# ----------------------------------------------------------------------------------------------- EDDI family, 2 ranks
+def _eddi_inputs(B, d, Ld, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, d, generator=g)
+    mask = torch.rand(B, d, generator=g) < 0.7
+    mask_p = mask & (torch.rand(B, d, generator=g) < 0.7)
+    return x, mask, mask_p, torch.randn(B, Ld, generator=g), torch.randn(B, Ld, generator=g)
+
+
+def _eddi_model(d, K, Ld, B):
+    torch.manual_seed(23)
+    return vpc.Reg_EDDI(d, 500, K, Ld, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
+
+
+def _eddi_gpu_worker(rank, world, port, d, B, K, Ld, steps, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    vpc.dp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    m = _eddi_model(d, K, Ld, B).to(dev)
+    vpc.dp.broadcast_parameters(m.flatten_parameters())
+    tr = vpc.EDDITrainer(m, world_size=world)
+    x, mask, mask_p, eq, ep = _eddi_inputs(B, d, Ld)
+    lo, hi = vpc.dp.shard_rows(B, rank, world)
+    losses = []
+    for i in range(steps):
+        tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eq[lo:hi].to(dev), ep[lo:hi].to(dev),
+                epoch=i + 1, alpha=0.5, global_batch=B)
+        losses.append(tr.loss_value())
+    if rank == 0:
+        out.put((losses, m._flat.cpu().numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_eddi_trainer_matches_single_process():
+    d, B, K, Ld, steps = 40, 257, 20, 10, 3  # uneven shards: 129 + 128 rows
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eddi_gpu_worker, args=(r, 2, port, d, B, K, Ld, steps, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses2, flat2 = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    m = _eddi_model(d, K, Ld, B).to(dev)
+    tr = vpc.EDDITrainer(m)
+    x, mask, mask_p, eq, ep = _eddi_inputs(B, d, Ld)
+    for i in range(steps):
+        tr.step(x.to(dev), mask.to(dev), mask_p.to(dev), eq.to(dev), ep.to(dev), epoch=i + 1, alpha=0.5)
+        assert abs(tr.loss_value() - losses2[i]) <= 5e-6 * abs(losses2[i]), (i, tr.loss_value(), losses2[i])
+    flat1 = m._flat.cpu().numpy()
+    assert np.max(np.abs(flat1 - flat2)) <= 3e-5 * np.max(np.abs(flat1))
