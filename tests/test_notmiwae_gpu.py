@@ -359,3 +359,40 @@ def test_graph_replay_equals_eager(nm, kind):
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("kind,d,K,Ld,B", [("reg", 200, 3, 12, 37), ("van", 256, 2, 64, 9), ("reg", 1, 4, 1, 5)])
+def test_wide_and_degenerate_shapes_vs_oracle(nm, kind, d, K, Ld, B):
+    """Shapes no golden covers - obs_dim in (128, 256] (4 feature slots per lane in the loss kernel), the maximum
+    latent width 64, obs_dim = latent_dim = 1 - against the torch port of the oracle (itself pinned to the
+    reference): loss 1e-4 relative, every parameter gradient 2e-4 of its max."""
+    from oracle import notmiwae_oracle as O
+    torch.manual_seed(d + K)
+    cls = nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion
+    model = cls(d, 128, 10, Ld, {"batch_size": B, "patience": 1}, K, 1)
+    p = {k: v.detach().clone().float().requires_grad_(True) for k, v in model.state_dict().items() if k in O.NM_KEYS}
+    model = model.cuda()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, d, generator=g)
+    m = (torch.rand(B, d, generator=g) < 0.6).float()
+    mp = m * (torch.rand(B, d, generator=g) < 0.5).float()
+    e1, e2 = torch.randn(B, K, Ld, generator=g), torch.randn(B, K, Ld, generator=g)
+    port = O.NMTorchPort(p, Ld, K, kind == "reg")
+    if kind == "reg":
+        ref = port.reg_loss(x, port.reg_forward(x, m, mp, e1, e2), m, mp, alpha=0.4)
+        zq, mq, lq = model._encode(x.cuda(), m.cuda(), eps=e1.cuda())
+        xmq, xlq = model.decoder(zq)
+        zp, mpn, lp = model._encode(x.cuda(), mp.cuda(), eps=e2.cuda())
+        xmp, xlp = model.decoder(zp)
+        _, tl = model.loss(x.cuda(), xmp, xlp, mpn, lp, xmq, xlq, mq, lq, m.cuda(), mp.cuda(), 1, alpha=0.4)
+    else:
+        ref = port.van_loss(x, port.van_forward(x, m, e1), m, e2)
+        z, mq, lq = model._encode(x.cuda(), m.cuda(), eps=e1.cuda())
+        xm, xl = model.decoder(z)
+        _, tl = model.loss(x.cuda(), xm, xl, mq, lq, 1, m.cuda(), eps_kl=e2.cuda())
+    assert abs(tl.item() - ref.item()) <= 1e-4 * abs(ref.item()), (tl.item(), ref.item())
+    ref.backward()
+    tl.backward()
+    for k, prm in model.named_parameters():
+        if k in p:
+            _close(prm.grad, p[k].grad, 2e-4, f"grad {k}")
