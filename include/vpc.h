@@ -250,15 +250,18 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
  * agg[b] = sum_j mask[b][j] relu(W [x_bj, x_bj E_j, t_j] + c), W = pnp_encoder1.0.weight [K][2+K], c its bias,
  * E = type_pars1 [d][K], t = type_bias1 [d].  The layer folds per feature into pre = x_bj A_j + C_j
  * (vpc_eddi_fold writes AC = [A | C], each [K][d]); nothing of size B*d*(2+K) is materialised.  d <= 128, K <= 32.
- * vpc_eddi_front_bwd: gradients of (E, t, W, c) from dagg [B][K]; scratch of vpc_eddi_front_scratch floats. */
+ * mask2 != NULL stacks a second pass over the same x (the mask / mask_p passes of one training step): agg and dagg
+ * then have 2B rows ([pass][B][K]) and the gradients are those of both passes.
+ * vpc_eddi_front_bwd: gradients of (E, t, W, c) from dagg; scratch of vpc_eddi_front_scratch(rows, d, K) floats with
+ * rows = B or 2B. */
 int vpc_eddi_fold(const float* E, const float* tb, const float* Wp, const float* cp, float* AC, int d, int K,
                   void* stream);
-int vpc_eddi_front_fwd(const float* x, const uint8_t* mask, const float* AC, float* agg, long B, int d, int K,
-                       void* stream);
-long vpc_eddi_front_scratch(long B, int d, int K);
-int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const float* AC, const float* dagg, const float* E,
-                       const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE, float* gtb,
-                       float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream);
+int vpc_eddi_front_fwd(const float* x, const uint8_t* mask, const uint8_t* mask2, const float* AC, float* agg, long B,
+                       int d, int K, void* stream);
+long vpc_eddi_front_scratch(long rows, int d, int K);
+int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2, const float* AC, const float* dagg,
+                       const float* E, const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE,
+                       float* gtb, float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -219,3 +219,31 @@ def test_fused_trainer_device_draws(ed):
         assert losses[-1] < losses[0]
         finals.append((losses, model._flat.clone()))
     assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
+
+
+def test_front_end_stacked_passes(ed):
+    """Two passes over the same x stacked in one launch (mask, mask_p) == the two single-pass calls: forward bitwise,
+    gradients equal to the sum of the per-pass gradients."""
+    rng = np.random.default_rng(3)
+    B, d, K = 130, 100, 20
+    x = _dev(rng.random((B, d), dtype=np.float32))
+    m0 = _dev((rng.random((B, d)) < 0.7).astype(np.uint8))
+    m1 = m0 * _dev((rng.random((B, d)) < 0.7).astype(np.uint8))
+    E, tb = _dev(rng.normal(size=(d, K)).astype(np.float32)), _dev(rng.normal(size=(d, 1)).astype(np.float32))
+    Wp, cp = _dev(rng.normal(size=(K, 2 + K)).astype(np.float32) * 0.3), _dev(rng.normal(size=K).astype(np.float32))
+    dagg = _dev(rng.normal(size=(2 * B, K)).astype(np.float32))
+    AC = torch.empty(2, K, d, device="cuda")
+    ed.eddi_fold(E, tb, Wp, cp, AC, d, K)
+    agg2 = torch.empty(2 * B, K, device="cuda")
+    ed.eddi_front_fwd(x, m0, AC, agg2, B, d, K, mask2_u8=m1)
+    a0, a1 = torch.empty(B, K, device="cuda"), torch.empty(B, K, device="cuda")
+    ed.eddi_front_fwd(x, m0, AC, a0, B, d, K)
+    ed.eddi_front_fwd(x, m1, AC, a1, B, d, K)
+    assert torch.equal(agg2[:B], a0) and torch.equal(agg2[B:], a1)
+    mk = lambda: [torch.zeros(s, device="cuda") for s in ((d, K), (d, 1), (K, 2 + K), (K,))]
+    g2, gs = mk(), mk()
+    ed.eddi_front_bwd(x, m0, AC, dagg, E, tb, Wp, *g2, B, d, K, mask2_u8=m1)
+    ed.eddi_front_bwd(x, m0, AC, dagg[:B].contiguous(), E, tb, Wp, *gs, B, d, K)
+    ed.eddi_front_bwd(x, m1, AC, dagg[B:].contiguous(), E, tb, Wp, *gs, B, d, K, accumulate=True)
+    for a, b in zip(g2, gs):
+        _close(a, b, 2e-6, "stacked vs per-pass gradients")

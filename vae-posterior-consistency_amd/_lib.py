@@ -70,9 +70,9 @@ _PROTOS = {
     "vpc_nm_prep": [P, P, P, P, L_, I, F, P, L_, ULL, ULL, ULL, P, P],
     # PNP / EDDI encoder front-end
     "vpc_eddi_fold": [P, P, P, P, P, I, I, P],
-    "vpc_eddi_front_fwd": [P, P, P, P, L_, I, I, P],
+    "vpc_eddi_front_fwd": [P, P, P, P, P, L_, I, I, P],
     "vpc_eddi_front_scratch": [L_, I, I],
-    "vpc_eddi_front_bwd": [P, P, P, P, P, P, P, P, L_, P, P, P, P, I, L_, I, I, P],
+    "vpc_eddi_front_bwd": [P, P, P, P, P, P, P, P, P, L_, P, P, P, P, I, L_, I, I, P],
 }
 _RESTYPE_LONG = {"vpc_linear_wgrad_scratch", "vpc_nm_loss_scratch", "vpc_eddi_front_scratch"}
 

@@ -28,10 +28,12 @@ __global__ void eddi_fold_kernel(const float* __restrict__ E, const float* __res
     AC[(long)(K + k) * d + j] = w[1 + K] * tb[j] + cp[k];
 }
 
+// rows r = pass * B + b: the passes of one step (mask, mask_p) are stacked, x is shared
 template <int T>
-__global__ __launch_bounds__(256) void eddi_front_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+__global__ __launch_bounds__(256) void eddi_front_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m0,
+                                                             const uint8_t* __restrict__ m1,
                                                              const float* __restrict__ AC, float* __restrict__ agg,
-                                                             int B, int d, int K) {
+                                                             int B, int npass, int d, int K) {
     extern __shared__ float lds[];  // [2][K][d]
     for (int i = threadIdx.x; i < 2 * K * d; i += blockDim.x) lds[i] = AC[i];
     __syncthreads();
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(256) void eddi_front_fwd_kernel(const float* __rest
     const float* sC = lds + K * d;
     const int lane = threadIdx.x & 63;
     const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int b = gwave; b < B; b += nwaves) {
+    for (int r = gwave; r < npass * B; r += nwaves) {
+        const int b = r < B ? r : r - B;
+        const uint8_t* __restrict__ m = r < B ? m0 : m1;
         float xv[T], mv[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -59,72 +63,90 @@ __global__ __launch_bounds__(256) void eddi_front_fwd_kernel(const float* __rest
             const float s = wave_sum_dpp(v);
             if (lane == k) out = s;
         }
-        if (lane < K) agg[(long)b * K + lane] = out;
+        if (lane < K) agg[(long)r * K + lane] = out;
     }
 }
 
 template <int T, int KP>
-__global__ __launch_bounds__(256) void eddi_front_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+__global__ __launch_bounds__(256) void eddi_front_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m0,
+                                                             const uint8_t* __restrict__ m1,
                                                              const float* __restrict__ AC,
                                                              const float* __restrict__ dagg, float* __restrict__ part,
-                                                             int B, int d, int K) {
-    extern __shared__ float lds[];  // [2][K][d], reused for the cross-wave combine ([4][2][K][d] needs 4x: see host)
+                                                             int B, int npass, int d, int K) {
+    extern __shared__ float lds[];  // [2][K][d] images, then the cross-wave combine stage [2][K][d]
     for (int i = threadIdx.x; i < 2 * K * d; i += blockDim.x) lds[i] = AC[i];
     __syncthreads();
     const float* sA = lds;
     const float* sC = lds + K * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int R = npass * B;
     float dA[KP][T], dC[KP][T];
 #pragma unroll
     for (int k = 0; k < KP; ++k)
 #pragma unroll
         for (int t = 0; t < T; ++t) dA[k][t] = dC[k][t] = 0.f;
-    for (int b = gwave; b < B; b += nwaves) {
-        float xv[T], mv[T];
+    // one row ahead: the loads of row r + nwaves are in flight while row r is accumulated (a wave has 2-3 dependent
+    // global loads per row and nothing else to overlap them with)
+    struct Row { float xv[T], mv[T], dg; };
+    auto fetch = [&](int r, Row& o) {
+        const int b = r < B ? r : r - B;
+        const uint8_t* __restrict__ m = r < B ? m0 : m1;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int j = lane + 64 * t;
             const bool ok = j < d;
-            xv[t] = ok ? x[(long)b * d + j] : 0.f;
-            mv[t] = (ok && m[(long)b * d + j]) ? 1.f : 0.f;
+            o.xv[t] = ok ? x[(long)b * d + j] : 0.f;
+            o.mv[t] = (ok && m[(long)b * d + j]) ? 1.f : 0.f;
         }
-        const float dg_lane = lane < K ? dagg[(long)b * K + lane] : 0.f;
+        o.dg = lane < K ? dagg[(long)r * K + lane] : 0.f;
+    };
+    Row cur, nxt;
+    if (gwave < R) fetch(gwave, cur);
+    for (int r = gwave; r < R; r += nwaves) {
+        if (r + nwaves < R) fetch(r + nwaves, nxt);
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             if (k < K) {  // wave-uniform; no `break`: the loop must unroll fully to keep dA / dC in registers
-                const float dg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dg_lane), k));
+                const float dg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur.dg), k));
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const int j = lane + 64 * t;
                     if (j < d) {
-                        const float pre = xv[t] * sA[k * d + j] + sC[k * d + j];
-                        const float g = pre > 0.f ? mv[t] * dg : 0.f;
-                        dA[k][t] += g * xv[t];
+                        const float pre = cur.xv[t] * sA[k * d + j] + sC[k * d + j];
+                        const float g = pre > 0.f ? cur.mv[t] * dg : 0.f;
+                        dA[k][t] += g * cur.xv[t];
                         dC[k][t] += g;
                     }
                 }
             }
         }
+        cur = nxt;
     }
-    // ---- combine the 4 waves in wave order through LDS (stage: [4][2][K][d])
-    __syncthreads();
-    float* st = lds + 2 * K * d;  // the host sizes the LDS for 2*K*d (images) + 4*2*K*d (stage)
+    // ---- combine the 4 waves through ONE stage of 2*K*d floats, wave after wave (fixed order => deterministic).  A
+    // stage per wave (4x the LDS) limited the kernel to one workgroup per CU, i.e. one wave per SIMD.
+    float* st = lds + 2 * K * d;
+    for (int ww = 0; ww < 4; ++ww) {
+        __syncthreads();
+        if (wave == ww) {
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
+            for (int k = 0; k < KP; ++k) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int j = lane + 64 * t;
-            if (k < K && j < d) {
-                st[((wave * 2 + 0) * K + k) * d + j] = dA[k][t];
-                st[((wave * 2 + 1) * K + k) * d + j] = dC[k][t];
+                for (int t = 0; t < T; ++t) {
+                    const int j = lane + 64 * t;
+                    if (k < K && j < d) {
+                        float* pa = st + k * d + j;
+                        float* pc = st + (K + k) * d + j;
+                        *pa = (ww == 0 ? 0.f : *pa) + dA[k][t];
+                        *pc = (ww == 0 ? 0.f : *pc) + dC[k][t];
+                    }
+                }
             }
         }
     }
     __syncthreads();
     const int n = 2 * K * d;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        part[(long)blockIdx.x * n + i] = (st[i] + st[n + i]) + (st[2 * n + i] + st[3 * n + i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) part[(long)blockIdx.x * n + i] = st[i];
 }
 
 // dAC[i] = sum over the workgroup partials (fixed order)
@@ -141,7 +163,8 @@ __global__ void eddi_reduce_kernel(const float* __restrict__ part, int G, int n,
     dAC[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// chain rule from (dA, dC) [K][d] to the four parameter tensors; one workgroup (d * K^2 MACs)
+// chain rule from (dA, dC) [K][d] to the four parameter tensors: one thread per output element
+// (d*K + d + K*(2+K) + K of them), each a short dot product
 __global__ __launch_bounds__(256) void eddi_param_bwd_kernel(const float* __restrict__ dAC, const float* __restrict__ E,
                                                              const float* __restrict__ tb, const float* __restrict__ Wp,
                                                              float* __restrict__ gE, float* __restrict__ gtb,
@@ -150,37 +173,42 @@ __global__ __launch_bounds__(256) void eddi_param_bwd_kernel(const float* __rest
     const float* dA = dAC;
     const float* dC = dAC + (long)K * d;
     auto put = [&](float* p, float v) { *p = accumulate ? *p + v : v; };
-    // dE[j][e] = sum_k W_E[k][e] dA[k][j];   dt[j] = sum_k w_t[k] dC[k][j]
-    for (int i = threadIdx.x; i < d * K; i += blockDim.x) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d * K) {  // dE[j][e] = sum_k W_E[k][e] dA[k][j]
         const int j = i / K, e = i % K;
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + e] * dA[(long)k * d + j];
         put(gE + i, s);
+        return;
     }
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    i -= d * K;
+    if (i < d) {  // dt[j] = sum_k w_t[k] dC[k][j]
         float s = 0.f;
-        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + K] * dC[(long)k * d + j];
-        put(gtb + j, s);
+        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + K] * dC[(long)k * d + i];
+        put(gtb + i, s);
+        return;
     }
-    // dW[k][0] = sum_j dA[k][j]; dW[k][1+e] = sum_j dA[k][j] E[j][e]; dW[k][1+K] = sum_j dC[k][j] t[j]; dc[k] = sum_j dC
-    for (int i = threadIdx.x; i < K * (2 + K); i += blockDim.x) {
+    i -= d;
+    if (i < K * (2 + K)) {  // dW[k][0] = sum_j dA; dW[k][1+e] = sum_j dA E[j][e]; dW[k][1+K] = sum_j dC t[j]
         const int k = i / (2 + K), c = i % (2 + K);
         float s = 0.f;
         if (c == 0) for (int j = 0; j < d; ++j) s += dA[(long)k * d + j];
         else if (c == 1 + K) for (int j = 0; j < d; ++j) s += dC[(long)k * d + j] * tb[j];
         else for (int j = 0; j < d; ++j) s += dA[(long)k * d + j] * E[(long)j * K + (c - 1)];
         put(gWp + i, s);
+        return;
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    i -= K * (2 + K);
+    if (i < K) {  // dc[k] = sum_j dC[k][j]
         float s = 0.f;
-        for (int j = 0; j < d; ++j) s += dC[(long)k * d + j];
-        put(gcp + k, s);
+        for (int j = 0; j < d; ++j) s += dC[(long)i * d + j];
+        put(gcp + i, s);
     }
 }
 
 static int eddi_blocks(long B) {
     long blocks = (B + 3) / 4;
-    const long cap = 2L * num_cus();
+    const long cap = 3L * num_cus();  // the backward kernel fits 3 workgroups per CU (registers)
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -200,49 +228,58 @@ int vpc_eddi_fold(const float* E, const float* tb, const float* Wp, const float*
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
-int vpc_eddi_front_fwd(const float* x, const uint8_t* mask, const float* AC, float* agg, long B, int d, int K,
-                       void* stream) {
-    if (!x || !mask || !AC || !agg || B <= 0 || B > 0x7fffff00L) return VPC_ERR_ARG;
+int vpc_eddi_front_fwd(const float* x, const uint8_t* mask, const uint8_t* mask2, const float* AC, float* agg, long B,
+                       int d, int K, void* stream) {
+    if (!x || !mask || !AC || !agg || B <= 0 || 2 * B > 0x7fffff00L) return VPC_ERR_ARG;
     if (d <= 0 || d > 128 || K <= 0 || K > EDDI_MAX_K) return VPC_ERR_SHAPE;
+    const int npass = mask2 ? 2 : 1;
     const size_t lds = 2 * (size_t)K * d * sizeof(float);
-    const int blocks = eddi_blocks(B) * 2;
+    const int blocks = eddi_blocks(npass * B) * 2;
     hipStream_t st = (hipStream_t)stream;
-    if (d <= 64) hipLaunchKernelGGL((eddi_front_fwd_kernel<1>), dim3(blocks), dim3(256), lds, st, x, mask, AC, agg, (int)B, d, K);
-    else hipLaunchKernelGGL((eddi_front_fwd_kernel<2>), dim3(blocks), dim3(256), lds, st, x, mask, AC, agg, (int)B, d, K);
+    if (d <= 64) hipLaunchKernelGGL((eddi_front_fwd_kernel<1>), dim3(blocks), dim3(256), lds, st, x, mask, mask2, AC, agg, (int)B, npass, d, K);
+    else hipLaunchKernelGGL((eddi_front_fwd_kernel<2>), dim3(blocks), dim3(256), lds, st, x, mask, mask2, AC, agg, (int)B, npass, d, K);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
-long vpc_eddi_front_scratch(long B, int d, int K) {  // floats: per-workgroup partials + reduced (dA | dC)
+long vpc_eddi_front_scratch(long B, int d, int K) {  // floats: per-workgroup partials + reduced (dA | dC); B = all rows
     if (B <= 0 || d <= 0 || K <= 0) return 0;
     return (long)(eddi_blocks(B) + 1) * 2 * K * d;
 }
 
-int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const float* AC, const float* dagg, const float* E,
-                       const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE, float* gtb,
-                       float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream) {
+int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2, const float* AC, const float* dagg,
+                       const float* E, const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE,
+                       float* gtb, float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream) {
     if (!x || !mask || !AC || !dagg || !E || !tb || !Wp || !scratch || !gE || !gtb || !gWp || !gcp || B <= 0 ||
-        B > 0x7fffff00L)
+        2 * B > 0x7fffff00L)
         return VPC_ERR_ARG;
     if (d <= 0 || d > 128 || K <= 0 || K > EDDI_MAX_K) return VPC_ERR_SHAPE;
-    if (scratch_floats < vpc_eddi_front_scratch(B, d, K)) return VPC_ERR_ARG;
-    const int G = eddi_blocks(B), n = 2 * K * d;
-    const size_t lds = (size_t)(2 + 8) * K * d * sizeof(float);
+    const int npass = mask2 ? 2 : 1;
+    if (scratch_floats < vpc_eddi_front_scratch(npass * B, d, K)) return VPC_ERR_ARG;
+    const int G = eddi_blocks(npass * B), n = 2 * K * d;
+    const size_t lds = (size_t)4 * K * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     float* part = scratch;
     float* dAC = scratch + (long)G * n;
 #define VPC_EDDI_BWD(T, KP)                                                                                          \
     do {                                                                                                             \
         if (!lds_attr_done(reinterpret_cast<const void*>(&eddi_front_bwd_kernel<T, KP>), lds)) return VPC_ERR_HIP;   \
-        hipLaunchKernelGGL((eddi_front_bwd_kernel<T, KP>), dim3(G), dim3(256), lds, st, x, mask, AC, dagg, part, (int)B, \
-                           d, K);                                                                                    \
+        hipLaunchKernelGGL((eddi_front_bwd_kernel<T, KP>), dim3(G), dim3(256), lds, st, x, mask, mask2, AC, dagg, part, \
+                           (int)B, npass, d, K);                                                                     \
     } while (0)
-    if (d <= 64) { if (K <= 16) VPC_EDDI_BWD(1, 16); else VPC_EDDI_BWD(1, 32); }
-    else { if (K <= 16) VPC_EDDI_BWD(2, 16); else VPC_EDDI_BWD(2, 32); }
+    // register accumulators are sized by K: exact variants for the reference's K = 10 / 20 (imputation_args.json)
+    if (d <= 64) {
+        if (K <= 10) VPC_EDDI_BWD(1, 10); else if (K <= 16) VPC_EDDI_BWD(1, 16);
+        else if (K <= 20) VPC_EDDI_BWD(1, 20); else VPC_EDDI_BWD(1, 32);
+    } else {
+        if (K <= 10) VPC_EDDI_BWD(2, 10); else if (K <= 16) VPC_EDDI_BWD(2, 16);
+        else if (K <= 20) VPC_EDDI_BWD(2, 20); else VPC_EDDI_BWD(2, 32);
+    }
 #undef VPC_EDDI_BWD
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
     hipLaunchKernelGGL(eddi_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, G, n, dAC);
-    hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3(1), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp, gcp, d, K,
-                       accumulate);
+    const int n_out = d * K + d + K * (2 + K) + K;
+    hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp,
+                       gcp, d, K, accumulate);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

@@ -29,17 +29,20 @@ def eddi_fold(E, tb, Wp, cp, AC, d, K):
     check(lib().vpc_eddi_fold(ptr(E), ptr(tb), ptr(Wp), ptr(cp), ptr(AC), d, K, stream_ptr()), "vpc_eddi_fold")
 
 
-def eddi_front_fwd(x, mask_u8, AC, agg, B, d, K):
-    check(lib().vpc_eddi_front_fwd(ptr(x), ptr(mask_u8), ptr(AC), ptr(agg), B, d, K, stream_ptr()),
+def eddi_front_fwd(x, mask_u8, AC, agg, B, d, K, mask2_u8=None):
+    """agg [B][K] (or [2B][K] when a second mask is given: the two passes of a step stacked)."""
+    check(lib().vpc_eddi_front_fwd(ptr(x), ptr(mask_u8), ptr(mask2_u8), ptr(AC), ptr(agg), B, d, K, stream_ptr()),
           "vpc_eddi_front_fwd")
 
 
-def eddi_front_bwd(x, mask_u8, AC, dagg, E, tb, Wp, gE, gtb, gWp, gcp, B, d, K, accumulate=False):
-    need = int(lib().vpc_eddi_front_scratch(B, d, K))
-    sc = torch.empty(need, device=x.device)
-    check(lib().vpc_eddi_front_bwd(ptr(x), ptr(mask_u8), ptr(AC), ptr(dagg), ptr(E), ptr(tb), ptr(Wp), ptr(sc), need,
-                                   ptr(gE), ptr(gtb), ptr(gWp), ptr(gcp), int(accumulate), B, d, K, stream_ptr()),
-          "vpc_eddi_front_bwd")
+def eddi_front_bwd(x, mask_u8, AC, dagg, E, tb, Wp, gE, gtb, gWp, gcp, B, d, K, accumulate=False, mask2_u8=None,
+                   scratch=None):
+    rows = B * (2 if mask2_u8 is not None else 1)
+    need = int(lib().vpc_eddi_front_scratch(rows, d, K))
+    sc = scratch if scratch is not None and scratch.numel() >= need else torch.empty(need, device=x.device)
+    check(lib().vpc_eddi_front_bwd(ptr(x), ptr(mask_u8), ptr(mask2_u8), ptr(AC), ptr(dagg), ptr(E), ptr(tb), ptr(Wp),
+                                   ptr(sc), sc.numel(), ptr(gE), ptr(gtb), ptr(gWp), ptr(gcp), int(accumulate), B, d, K,
+                                   stream_ptr()), "vpc_eddi_front_bwd")
 
 
 class EDDIEncoderFn(torch.autograd.Function):
@@ -271,6 +274,7 @@ class EDDITrainer:
         self.dheads, self.dh2, self.dh1, self.dagg = e(P * B, 2 * Ld), e(P * B, H2), e(P * B, H1), e(P * B, K)
         self.eps_buf = e(3, B, LP)
         self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
+        self.front_scratch = e(int(lib().vpc_eddi_front_scratch(P * B, d, K)))
         self._B = B
 
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=0.5, beta=1.0,
@@ -316,8 +320,7 @@ class EDDITrainer:
         masks = [mask, mask_p] if two else [mask]
         # ---- encoder: front-end per pass, trunk on the stacked passes
         eddi_fold(E, tb, Wp, cp, self.AC, d, K)
-        for p_, mk in enumerate(masks):
-            eddi_front_fwd(x, mk, self.AC, self.agg[p_ * B:(p_ + 1) * B], B, d, K)
+        eddi_front_fwd(x, masks[0], self.AC, self.agg, B, d, K, masks[1] if two else None)  # both passes, one launch
         R = P * B
         linear_fwd(self.agg, W1, b1, self.h1, R, H1, K, ACT_RELU)
         linear_fwd(self.h1, W2, b2, self.h2, R, H2, H1, ACT_RELU)
@@ -348,9 +351,8 @@ class EDDITrainer:
         linear_dgrad(self.dh2, W2, self.dh1, R, H2, H1, x_out=self.h1, act_prev=ACT_RELU)
         linear_wgrad(self.dh1, self.agg, g[0], g[1], R, H1, K)
         linear_dgrad(self.dh1, W1, self.dagg, R, H1, K)
-        for p_, mk in enumerate(masks):
-            eddi_front_bwd(x, mk, self.AC, self.dagg[p_ * B:(p_ + 1) * B], E, tb, Wp, g[12], g[13], g[14], g[15], B, d,
-                           K, accumulate=p_ > 0)
+        eddi_front_bwd(x, masks[0], self.AC, self.dagg, E, tb, Wp, g[12], g[13], g[14], g[15], B, d, K,
+                       mask2_u8=masks[1] if two else None, scratch=self.front_scratch)
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
