@@ -13,67 +13,10 @@
 // The additive constant 0.5*log(2 pi) per element of every NLL term is added on the host.
 #include "vpc_device.h"
 #include "vpc_abi_internal.h"
+#include "vpc_dec_args.h"
 #include <cstdlib>
 
 namespace vpc {
-
-enum { MODE_FWD = 0, MODE_FUSED = 1, MODE_BWD = 2 };
-
-struct DecArgs {
-    const float* x;
-    const float* img;
-    const uint8_t* mA[2];
-    const uint8_t* mB[2];
-    float cA[2], cE[2];
-    const float* mean[2];
-    const float* logvar[2];
-    const float* eps[2];
-    const float* eps_ml;
-    const float* z_in[2];
-    const float* dxhat[2];
-    float* xhat[2];
-    float* dmean[2];
-    float* dlogvar[2];
-    float* dz[2];
-    float* part;
-    double* loss_part;
-    float bq, bp, cr, wml, inv_B, x_logvar;
-    long B;
-    int d, L, npass, ntiles;
-    int lp;   // row pitch of the [B][.] latent arrays: L (dense, API tensors) or 16 (padded workspaces)
-    int dbg;  // ablation mask, only honoured by the diagnostic build (-DVPC_ABLATE); 0 in the product build
-};
-
-// VPC_DBG(bit) guards the ablation switches of the diagnostic build (tools/ablate.sh).  In the product build it
-// is an always-false test of a value the optimiser cannot see through: the switches cost one s_cbranch each
-// and, more importantly, cut the kernel's 17k-line straight-line body into scheduling regions.  hipcc's
-// scheduler otherwise hoists loads across the whole body, overshoots the 512-register budget and spills
-// (measured on MI355X: 326 us without the region cuts, 252 us with them).
-#ifdef VPC_ABLATE
-#define VPC_DBG(bit) ((a.dbg & (bit)) != 0)
-// phase timing (diagnostic build only): accumulate s_memtime deltas per phase, printed by block 0 / thread 0
-#define VPC_STAMP(i)                                        \
-    do {                                                    \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        T[i] += t_ - tlast;                                 \
-        tlast = t_;                                         \
-    } while (0)
-#else
-#define VPC_STAMP(i) do {} while (0)
-__device__ __forceinline__ int opaque_zero() {
-    int z;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-    return z;
-}
-#define VPC_DBG(bit) ((opaque_zero() & (bit)) != 0)
-#endif
-// scheduling-region cut with no other effect (a never-taken branch around an empty asm)
-#define VPC_CUT()                                              \
-    do {                                                       \
-        if (VPC_DBG(0x4000)) asm volatile("s_nop 0");          \
-    } while (0)
-
-constexpr int DEC_CH = 64;  // batch rows per wgrad staging chunk = batch tile nb of all 4 waves
 
 // One wave per SIMD (4 waves, up to 512 registers each), every wave owns NB = 2 batch tiles of 16 rows:
 // the whole per-pass live set (activations of both tiles + 92 wgrad accumulators) stays in registers, each
@@ -632,5 +575,8 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     }
     if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
     if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
+    // experiment switch: the 8-wave / one-tile-per-wave variant (vpc_dec8.hip), d in (64, 128] only
+    static const bool use8 = [] { const char* e = getenv("VPC_DEC8"); return e && atoi(e) != 0; }();
+    if (use8 && dt_for(d) == 8) return dec8_dispatch(a, vec, (hipStream_t)stream);
     return dispatch<MODE_FUSED>(a, vec, (hipStream_t)stream);
 }

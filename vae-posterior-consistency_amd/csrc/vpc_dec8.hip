@@ -1,0 +1,376 @@
+// Fused decoder kernel, 8-wave variant: TWO waves per SIMD, ONE 16-row batch tile per wave.
+//
+// Same mathematics, LDS images, staging buffers and partial-block layout as dec_kernel<.., MODE_FUSED> in vpc_dec.hip
+// (4 waves x 2 batch tiles, one wave per SIMD); what changes is who hides latency.  In the 4-wave kernel everything a
+// wave waits for (LDS fragment reads, the VALU of the loss behind the MFMAs of an output tile) is exposed unless the
+// compiler interleaves it inside that one wave, and hipcc can only do that by keeping both tiles' state live, which
+// spills.  Here the second wave of the SIMD fills those gaps in hardware; the price is one MFMA chain per wave
+// (dependent-issue latency) and half the registers per wave (256), which the smaller per-wave state fits:
+//   wgrad accumulators 48 (dW6 tile w x 7, dW5 tile w < 7 x 4, dW4 tile w < 4), g1 16, g2 28, dpre 32, latent 16.
+// wgrad staging keeps the 64-column buffers: two rounds per phase, waves 4r..4r+3 stage their tile in round r and all
+// 8 waves multiply.  Partial blocks are written in the 4-wave layout (out tile mt of dW6 lives at wave mt & 3,
+// registers 28 (mt >> 2) + ...), so the host-side index tables and the reduction do not change.
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "vpc_dec_args.h"
+
+namespace vpc {
+
+constexpr int DEC8_WAVES = 8, DEC8_THREADS = 512;
+
+template <int DT, bool VEC>
+__global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CH = DEC_CH;
+    constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
+    const DecImg im(DT);
+    load_image(lds, a.img, im.total);
+    const float* W4 = lds + im.oW4;
+    const float* W5 = lds + im.oW5;
+    const float* W6 = lds + im.oW6;
+    float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
+    float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
+    float* red = stB + H1P * CH;   // [8][LOSS_TERMS]
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int round_w = w >> 2;                 // staging round in which this wave writes
+    int sb[4];
+    stage_bases<CH>(sb, 16 * (w & 3), c, q);
+    const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
+    constexpr float HL2PI = 0.91893853320467274f;
+    const bool own6 = w < DT, own5 = w < H1T, own4 = w < H2T;
+
+    auto ld_lat = [&](const float* base, long r, bool rok) -> f32x4 { return ld_tile_o<true>(base, r, 16, 4 * q, 16, rok); };
+    auto st_lat = [&](float* base, long r, bool rok, f32x4 v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (4 * q + j < a.L) ? v[j] : 0.f;
+        st_tile<true>(base, r, 16, 4 * q, 16, rok, v);
+    };
+
+    f32x4 acc6[H1T], acc5[H2T], acc4 = zero4();
+#pragma unroll
+    for (int t = 0; t < H1T; ++t) acc6[t] = zero4();
+#pragma unroll
+    for (int t = 0; t < H2T; ++t) acc5[t] = zero4();
+    float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long row = (long)tile * TILE_ROWS + w * 16 + c;
+        const bool ok = row < a.B;
+        for (int p = 0; p < a.npass; ++p) {
+            asm volatile("" ::: "memory");  // keep LDS weight reads inside the pass (see vpc_enc.hip)
+            int cc = c, qq = q;
+            launder(cc, qq);
+            // ---------------- latent: z = mean + eps * exp(logvar / 2), KL terms and their seeds
+            f32x4 z[1][1], epsfac, dmu_kl, dlv_kl;
+            {
+                const bool two = a.npass == 2;
+                const f32x4 mu = ld_lat(a.mean[p], row, ok);
+                const f32x4 lv = ld_lat(a.logvar[p], row, ok);
+                f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
+                const uint32_t has_o = opaque_mask(two);
+                const f32x4 mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row, ok), has_o);
+                const f32x4 lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row, ok), has_o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sig = __expf(0.5f * lv[j]);
+                    z[0][0][j] = mu[j] + e[j] * sig;
+                    epsfac[j] = e[j] * 0.5f * sig;
+                }
+                const float b0 = (p == 0) ? a.bq : a.bp;
+                const float sgn = (p == 0) ? 1.f : -1.f;
+                const float crr = two ? a.cr : 0.f;
+                float kl0 = 0.f, klr = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float elv = __expf(lv[j]);
+                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
+                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
+                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
+                    const float dl = b0 * 0.5f * (elv - 1.f) +
+                                     crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
+                    dmu_kl[j] = dm * a.inv_B;
+                    dlv_kl[j] = dl * a.inv_B;
+                }
+                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
+                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+                    f32x4 e3 = ld_lat(a.eps_ml, row, ok);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e3[j] = (4 * q + j < a.L) ? e3[j] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = ok && 4 * q + j < a.L;
+                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
+                        const float dlt = mq + e3[j] * sq - mp;
+                        const float g = a.wml * dlt * eip * a.inv_B;
+                        if (p == 0) {
+                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                            dmu_kl[j] += g;
+                            dlv_kl[j] += g * e3[j] * 0.5f * sq;
+                        } else {
+                            dmu_kl[j] -= g;
+                            dlv_kl[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
+                        }
+                    }
+                }
+            }
+            VPC_CUT();
+            const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
+            f32x4 dzt[1] = {zero4()};
+            if (!skip_dec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * q + j == a.L) z[0][0][j] = 1.f;  // constant feature that drives the bias chain
+                // ---------------- decoder forward
+                f32x4 g1[1][H2T], g2[1][H1T];
+#pragma unroll
+                for (int mt = 0; mt < H2T; ++mt) {
+                    f32x4 acc[1] = {zero4()};
+                    tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
+                    g1[0][mt] = relu4(acc[0]);
+                }
+                VPC_CUT();
+                launder(cc, qq);
+#pragma unroll
+                for (int mt = 0; mt < H1T; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[1] = {zero4()};
+                    tile_fwd_nb<H2T, 64, 1>(W5, mt, g1, acc, cc, qq);
+                    g2[0][mt] = relu4(acc[0]);
+                }
+                launder(cc, qq);
+                VPC_CUT();
+                // ---------------- output tiles: forward, loss terms, d/d pre-activation
+                f32x4 dpre[1][DT];
+                float sa = 0.f, se = 0.f;
+                const bool hasB = a.mB[p] != nullptr;
+                const float hasBf = hasB ? 1.f : 0.f;
+                const float* xl;
+                const uint32_t* mal;
+                const uint32_t* mbl;
+                {
+                    const int cq = (VEC && 4 * q + 3 < a.d) ? 4 * q : 0;
+                    const long ro = (ok ? row : 0) * a.d + cq;
+                    xl = a.x + ro;
+                    mal = reinterpret_cast<const uint32_t*>(a.mA[p] + ro);
+                    mbl = reinterpret_cast<const uint32_t*>((hasB ? a.mB[p] : a.mA[p]) + ro);
+                }
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    VPC_CUT();
+                    const int f0 = 16 * mt + 4 * q;
+                    f32x4 xv;
+                    uint32_t ua, ub;
+                    if (VEC) {
+                        const bool colok = f0 + 3 < a.d;
+                        const int fo = colok ? 16 * mt : 0;
+                        const uint32_t vm = opaque_mask(ok && colok);
+                        xv = and4(*reinterpret_cast<const f32x4*>(xl + fo), vm);
+                        ua = mal[fo >> 2] & vm;
+                        ub = mbl[fo >> 2] & vm;
+                    } else {
+                        xv = ld_tile<false>(a.x, row, a.d, f0, a.d, ok);
+                        ua = ld_mask_raw<false>(a.mA[p], row, a.d, f0, a.d, ok);
+                        ub = hasB ? ld_mask_raw<false>(a.mB[p], row, a.d, f0, a.d, ok) : 0u;
+                    }
+                    f32x4 pre[1] = {zero4()};
+                    tile_fwd_nb<H1T, 128, 1>(W6, mt, g2, pre, cc, qq);
+                    const f32x4 mA = mask_to_f32(ua);
+                    const f32x4 mE = mA * (1.f - mask_to_f32(ub)) * hasBf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = fast_sigmoid(pre[0][j]);
+                        const float diff = xh - xv[j];
+                        const float t = half_lv + 0.5f * diff * diff * inv_s2;
+                        sa += mA[j] * t;
+                        se += mE[j] * t;
+                        const float dxh = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
+                        dpre[0][mt][j] = dxh * xh * (1.f - xh);
+                    }
+                }
+                VPC_CUT();
+                if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
+                const uint32_t gm2 = relu_bits<H1T>(g2[0]), gm1 = relu_bits<H2T>(g1[0]);
+                // ---------------- dW6~ += dpre * g2^T   (owner: wave w -> out tile w; all 7 in tiles)
+                VPC_CUT();
+                launder(cc, qq);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    __syncthreads();
+                    if (round_w == r) {
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[0][t], sb);
+#pragma unroll
+                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[0][t], sb);
+                    }
+                    __syncthreads();
+                    if (own6) {
+#pragma unroll
+                        for (int s = 0; s < CH / 16; ++s) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                            f32x4 fb_cur = stage_frag<CH>(stB, 0, s, cc, qq);
+#pragma unroll
+                            for (int nt = 0; nt < H1T; ++nt) {
+                                const f32x4 fb_nxt = stage_frag<CH>(stB, nt + 1 < H1T ? nt + 1 : nt, s, cc, qq);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc6[nt] = VPC_MFMA(fa[j], fb_cur[j], acc6[nt]);
+                                fb_cur = fb_nxt;
+                            }
+                        }
+                    }
+                }
+                // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
+                VPC_CUT();
+                launder(cc, qq);
+                f32x4 dg2[1][H1T];
+#pragma unroll
+                for (int mt = 0; mt < H1T; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[1] = {zero4()};
+                    VPC_CUT();
+                    tile_T_nb<DT, 128, 1>(W6, mt, dpre, acc, cc, qq);
+                    dg2[0][mt] = gate_bits(acc[0], gm2, mt);
+                }
+                // ---------------- dW5~ += dg2 * g1^T   (owner: wave w < 7 -> out tile w; 4 in tiles)
+                VPC_CUT();
+                launder(cc, qq);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    __syncthreads();
+                    if (round_w == r) {
+#pragma unroll
+                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[0][t], sb);
+#pragma unroll
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[0][t], sb);
+                    }
+                    __syncthreads();
+                    if (own5) {
+#pragma unroll
+                        for (int s = 0; s < CH / 16; ++s) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                            f32x4 fb_cur = stage_frag<CH>(stB, 0, s, cc, qq);
+#pragma unroll
+                            for (int nt = 0; nt < H2T; ++nt) {
+                                const f32x4 fb_nxt = stage_frag<CH>(stB, nt + 1 < H2T ? nt + 1 : nt, s, cc, qq);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc5[nt] = VPC_MFMA(fa[j], fb_cur[j], acc5[nt]);
+                                fb_cur = fb_nxt;
+                            }
+                        }
+                    }
+                }
+                // ---------------- dg1 = relu'(g1) * (W5~^T dg2)
+                VPC_CUT();
+                launder(cc, qq);
+                f32x4 dg1[1][H2T];
+#pragma unroll
+                for (int mt = 0; mt < H2T; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[1] = {zero4()};
+                    VPC_CUT();
+                    tile_T_nb<H1T, 64, 1>(W5, mt, dg2, acc, cc, qq);
+                    dg1[0][mt] = gate_bits(acc[0], gm1, mt);
+                }
+                // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
+                VPC_CUT();
+                launder(cc, qq);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    __syncthreads();
+                    if (round_w == r) {
+#pragma unroll
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[0][t], sb);
+                        stage_write_b<CH>(stB, 0, z[0][0], sb);
+                    }
+                    __syncthreads();
+                    if (own4) {
+#pragma unroll
+                        for (int s = 0; s < CH / 16; ++s) {
+                            const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
+                            const f32x4 fb = stage_frag<CH>(stB, 0, s, cc, qq);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc4 = VPC_MFMA(fa[j], fb[j], acc4);
+                        }
+                    }
+                }
+                launder(cc, qq);
+                tile_T_nb<H2T, S4, 1>(W4, 0, dg1, dzt, cc, qq);
+            }
+            // total seeds on the encoder outputs: KL part + reparameterisation path
+            st_lat(a.dmean[p], row, ok, dmu_kl + dzt[0]);
+            st_lat(a.dlogvar[p], row, ok, dlv_kl + dzt[0] * epsfac);
+        }
+    }
+    // ---- partial block in the layout of the 4-wave kernel (vpc_layout.h): out tile mt of dW6 -> wave mt & 3, regs
+    // 28 (mt >> 2) + 4 nt + j;  dW5 tile mt -> wave mt & 3, regs 56 + 16 (mt >> 2) + 4 nt + j;  dW4 tile mt -> wave mt, 88 + j
+    float* part = a.part + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
+    const int hi = w >> 2;
+    if (own6) {
+#pragma unroll
+        for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = acc6[nt][j];
+    } else {  // out tiles this model does not have (DT < 8): the slot still has to hold zeros for the reduction
+#pragma unroll
+        for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < H2T; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(56 + 16 * hi + 4 * nt + j) * 64] = own5 ? acc5[nt][j] : 0.f;
+    if (own4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
+    }
+    const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LOSS_TERMS; ++i) {
+        const float v = wave_sum(s[i]);
+        if (lane == 0) red[w * LOSS_TERMS + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_TERMS) {
+        double t = 0.0;
+        for (int k = 0; k < DEC8_WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+    }
+}
+
+size_t dec8_lds(int DT) {
+    const DecImg im(DT);
+    const int na = 16 * DT > H1P ? 16 * DT : H1P;
+    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + DEC8_WAVES * LOSS_TERMS);
+}
+
+// FUSED mode through the 8-wave kernel; returns VPC_ERR_SHAPE when this variant does not cover the shape
+int dec8_dispatch(const DecArgs& a, bool vec, hipStream_t s) {
+    const int DT = dt_for(a.d);
+    const size_t lds = dec8_lds(DT);
+    const int grid = a.ntiles < num_cus() ? a.ntiles : num_cus();
+#define VPC_CASE8(T)                                                                                         \
+    case T: {                                                                                                \
+        auto kern = vec ? dec8_kernel<T, true> : dec8_kernel<T, false>;                                      \
+        if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC8_THREADS), lds, s, a);                                 \
+        return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;                                       \
+    }
+    switch (DT) { VPC_CASE8(8) }
+#undef VPC_CASE8
+    return VPC_ERR_SHAPE;
+}
+
+}  // namespace vpc
