@@ -121,6 +121,10 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
             }
+            // the KL seeds are parked in the output arrays now and picked up again when dz is known: 8 registers that
+            // would otherwise be live across the whole pass (this kernel has 256 per wave)
+            st_lat(a.dmean[p], row, ok, dmu_kl);
+            st_lat(a.dlogvar[p], row, ok, dlv_kl);
             VPC_CUT();
             const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
             f32x4 dzt[1] = {zero4()};
@@ -194,10 +198,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         const float dxh = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
                         dpre[0][mt][j] = dxh * xh * (1.f - xh);
                     }
+                    // pin this tile's VALU here: without a volatile use hipcc sinks the sigmoid / loss code of ALL tiles
+                    // below the loop (next to the first use of dpre), keeping 8 tiles of pre / x / masks live
+                    asm volatile("" : "+v"(dpre[0][mt][0]), "+v"(dpre[0][mt][1]), "+v"(dpre[0][mt][2]), "+v"(dpre[0][mt][3]),
+                                      "+v"(sa), "+v"(se));
                 }
                 VPC_CUT();
                 if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
-                const uint32_t gm2 = relu_bits<H1T>(g2[0]), gm1 = relu_bits<H2T>(g1[0]);
+                const uint32_t gm2 = relu_bits<H1T>(g2[0]);
                 // ---------------- dW6~ += dpre * g2^T   (owner: wave w -> out tile w; all 7 in tiles)
                 VPC_CUT();
                 launder(cc, qq);
@@ -243,6 +251,15 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 // ---------------- dW5~ += dg2 * g1^T   (owner: wave w < 7 -> out tile w; 4 in tiles)
                 VPC_CUT();
                 launder(cc, qq);
+                // g1 is RECOMPUTED here (16 MFMAs from z) instead of being kept live since the forward pass: 16 registers
+                f32x4 g1b[1][H2T];
+#pragma unroll
+                for (int mt = 0; mt < H2T; ++mt) {
+                    f32x4 acc[1] = {zero4()};
+                    tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
+                    g1b[0][mt] = relu4(acc[0]);
+                }
+                const uint32_t gm1 = relu_bits<H2T>(g1b[0]);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     __syncthreads();
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[0][t], sb);
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[0][t], sb);
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1b[0][t], sb);
                     }
                     __syncthreads();
                     if (own5) {
@@ -307,9 +324,12 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
                 tile_T_nb<H2T, S4, 1>(W4, 0, dg1, dzt, cc, qq);
             }
-            // total seeds on the encoder outputs: KL part + reparameterisation path
-            st_lat(a.dmean[p], row, ok, dmu_kl + dzt[0]);
-            st_lat(a.dlogvar[p], row, ok, dlv_kl + dzt[0] * epsfac);
+            // total seeds on the encoder outputs: KL part (parked above) + reparameterisation path
+            if (!skip_dec) {
+                const f32x4 dm0 = ld_lat(a.dmean[p], row, ok), dl0 = ld_lat(a.dlogvar[p], row, ok);
+                st_lat(a.dmean[p], row, ok, dm0 + dzt[0]);
+                st_lat(a.dlogvar[p], row, ok, dl0 + dzt[0] * epsfac);
+            }
         }
     }
     // ---- partial block in the layout of the 4-wave kernel (vpc_layout.h): out tile mt of dW6 -> wave mt & 3, regs
