@@ -18,6 +18,52 @@ namespace vpc {
 
 constexpr int DEC8_WAVES = 8, DEC8_THREADS = 512;
 
+// Single-chain tile products with a 2-deep fragment pipeline: the second wave of the SIMD hides LDS latency here, so
+// only two A fragments are in flight (8 registers) instead of the whole tile's (up to 32) as in the 4-wave kernel.
+template <int KT, int S>
+__device__ __forceinline__ f32x4 tile_fwd_p2(const float* W, int mt, const f32x4 (&in)[KT], int m, int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const float* rowp = W + (16 * mt + m) * S;
+    f32x4 acc = zero4();
+    f32x4 fa = *reinterpret_cast<const f32x4*>(rowp + 4 * ((0 + q) ^ (m & MASK)));
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int kn = kt + 1 < KT ? kt + 1 : kt;
+        const f32x4 fn = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kn + q) ^ (m & MASK)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(fa[j], in[kt][j], acc);
+        fa = fn;
+    }
+    return acc;
+}
+template <int KT, int S>
+__device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (&in)[KT], int m, int q) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const int col = 16 * mt + m;
+    const int cs = col >> 2, cl = col & 3;
+    auto rd = [&](int kt) {
+        f32x4 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            f[j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
+        }
+        return f;
+    };
+    f32x4 acc = zero4();
+    f32x4 fa = rd(0);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 fn = rd(kt + 1 < KT ? kt + 1 : kt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(fa[j], in[kt][j], acc);
+        fa = fn;
+    }
+    return acc;
+}
+
 template <int DT, bool VEC>
 __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -62,7 +108,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             int cc = c, qq = q;
             launder(cc, qq);
             // ---------------- latent: z = mean + eps * exp(logvar / 2), KL terms and their seeds
-            f32x4 z[1][1], epsfac, dmu_kl, dlv_kl;
+            f32x4 z[1][1], dmu_kl, dlv_kl;
             {
                 const bool two = a.npass == 2;
                 const f32x4 mu = ld_lat(a.mean[p], row, ok);
@@ -77,7 +123,6 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const float sig = __expf(0.5f * lv[j]);
                     z[0][0][j] = mu[j] + e[j] * sig;
-                    epsfac[j] = e[j] * 0.5f * sig;
                 }
                 const float b0 = (p == 0) ? a.bq : a.bp;
                 const float sgn = (p == 0) ? 1.f : -1.f;
@@ -145,9 +190,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[1] = {zero4()};
-                    tile_fwd_nb<H2T, 64, 1>(W5, mt, g1, acc, cc, qq);
-                    g2[0][mt] = relu4(acc[0]);
+                    g2[0][mt] = relu4(tile_fwd_p2<H2T, 64>(W5, mt, g1[0], cc, qq));
                 }
                 launder(cc, qq);
                 VPC_CUT();
@@ -184,8 +227,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         ua = ld_mask_raw<false>(a.mA[p], row, a.d, f0, a.d, ok);
                         ub = hasB ? ld_mask_raw<false>(a.mB[p], row, a.d, f0, a.d, ok) : 0u;
                     }
-                    f32x4 pre[1] = {zero4()};
-                    tile_fwd_nb<H1T, 128, 1>(W6, mt, g2, pre, cc, qq);
+                    f32x4 pre[1];
+                    pre[0] = tile_fwd_p2<H1T, 128>(W6, mt, g2[0], cc, qq);
                     const f32x4 mA = mask_to_f32(ua);
                     const f32x4 mE = mA * (1.f - mask_to_f32(ub)) * hasBf;
 #pragma unroll
@@ -243,10 +286,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[1] = {zero4()};
                     VPC_CUT();
-                    tile_T_nb<DT, 128, 1>(W6, mt, dpre, acc, cc, qq);
-                    dg2[0][mt] = gate_bits(acc[0], gm2, mt);
+                    dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
                 }
                 // ---------------- dW5~ += dg2 * g1^T   (owner: wave w < 7 -> out tile w; 4 in tiles)
                 VPC_CUT();
@@ -294,10 +335,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[1] = {zero4()};
                     VPC_CUT();
-                    tile_T_nb<H1T, 64, 1>(W5, mt, dg2, acc, cc, qq);
-                    dg1[0][mt] = gate_bits(acc[0], gm1, mt);
+                    dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64>(W5, mt, dg2[0], cc, qq), gm1, mt);
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
                 VPC_CUT();
@@ -327,8 +366,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             // total seeds on the encoder outputs: KL part (parked above) + reparameterisation path
             if (!skip_dec) {
                 const f32x4 dm0 = ld_lat(a.dmean[p], row, ok), dl0 = ld_lat(a.dlogvar[p], row, ok);
+                // eps * exp(logvar / 2) / 2 is re-derived from its inputs here rather than carried through the pass
+                const f32x4 lv2 = ld_lat(a.logvar[p], row, ok);
+                f32x4 e2 = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
+                f32x4 ef;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ef[j] = (4 * q + j < a.L) ? e2[j] * 0.5f * __expf(0.5f * lv2[j]) : 0.f;
                 st_lat(a.dmean[p], row, ok, dm0 + dzt[0]);
-                st_lat(a.dlogvar[p], row, ok, dl0 + dzt[0] * epsfac);
+                st_lat(a.dlogvar[p], row, ok, dl0 + dzt[0] * ef);
             }
         }
     }
