@@ -67,6 +67,10 @@ __device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (
 template <int DT, bool VEC>
 __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VPC_ABLATE
+    unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int CH = DEC_CH;
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
     const DecImg im(DT);
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
     float* red = stB + H1P * CH;   // [8][LOSS_TERMS]
     __syncthreads();
+    VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int round_w = w >> 2;                 // staging round in which this wave writes
     int sb[4];
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             // would otherwise be live across the whole pass (this kernel has 256 per wave)
             st_lat(a.dmean[p], row, ok, dmu_kl);
             st_lat(a.dlogvar[p], row, ok, dlv_kl);
+            VPC_STAMP(1);
             VPC_CUT();
             const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
             f32x4 dzt[1] = {zero4()};
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     g2[0][mt] = relu4(tile_fwd_p2<H2T, 64>(W5, mt, g1[0], cc, qq));
                 }
                 launder(cc, qq);
+                VPC_STAMP(2);
                 VPC_CUT();
                 // ---------------- output tiles: forward, loss terms, d/d pre-activation
                 f32x4 dpre[1][DT];
@@ -209,26 +216,39 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     mal = reinterpret_cast<const uint32_t*>(a.mA[p] + ro);
                     mbl = reinterpret_cast<const uint32_t*>((hasB ? a.mB[p] : a.mA[p]) + ro);
                 }
-#pragma unroll
-                for (int mt = 0; mt < DT; ++mt) {
-                    VPC_CUT();
+                // x / mask words of tile mt + 1 are requested before tile mt's MFMAs and consumed after the next tile's: a
+                // wave never sits on a vmcnt wait in front of its MFMAs.  Out-of-range rows / columns read row 0 /
+                // column 0 (valid memory); their mask words are cleared below, so they carry zero weight.
+                auto fetch = [&](int mt, f32x4& xv, uint32_t& ua, uint32_t& ub) {
                     const int f0 = 16 * mt + 4 * q;
-                    f32x4 xv;
-                    uint32_t ua, ub;
                     if (VEC) {
-                        const bool colok = f0 + 3 < a.d;
-                        const int fo = colok ? 16 * mt : 0;
-                        const uint32_t vm = opaque_mask(ok && colok);
-                        xv = and4(*reinterpret_cast<const f32x4*>(xl + fo), vm);
-                        ua = mal[fo >> 2] & vm;
-                        ub = mbl[fo >> 2] & vm;
+                        // d > 16 * DT / 2 (dt_for): the first DT / 2 tiles have no out-of-range columns and are immediate offsets
+                        const int fo = (mt < DT / 2 || f0 + 3 < a.d) ? 16 * mt : 0;
+                        xv = *reinterpret_cast<const f32x4*>(xl + fo);
+                        ua = mal[fo >> 2];
+                        ub = mbl[fo >> 2];
                     } else {
                         xv = ld_tile<false>(a.x, row, a.d, f0, a.d, ok);
                         ua = ld_mask_raw<false>(a.mA[p], row, a.d, f0, a.d, ok);
                         ub = hasB ? ld_mask_raw<false>(a.mB[p], row, a.d, f0, a.d, ok) : 0u;
                     }
+                };
+                f32x4 xv_n;
+                uint32_t ua_n, ub_n;
+                fetch(0, xv_n, ua_n, ub_n);
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    VPC_CUT();
+                    const f32x4 xv = xv_n;
+                    uint32_t ua = ua_n, ub = ub_n;
+                    if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
                     f32x4 pre[1];
                     pre[0] = tile_fwd_p2<H1T, 128>(W6, mt, g2[0], cc, qq);
+                    if (VEC) {
+                        const uint32_t vm = opaque_mask(ok && (mt < DT / 2 || 16 * mt + 4 * q + 3 < a.d));
+                        ua &= vm;
+                        ub &= vm;
+                    }
                     const f32x4 mA = mask_to_f32(ua);
                     const f32x4 mE = mA * (1.f - mask_to_f32(ub)) * hasBf;
 #pragma unroll
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     asm volatile("" : "+v"(dpre[0][mt][0]), "+v"(dpre[0][mt][1]), "+v"(dpre[0][mt][2]), "+v"(dpre[0][mt][3]),
                                       "+v"(sa), "+v"(se));
                 }
+                VPC_STAMP(3);
                 VPC_CUT();
                 if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
                 const uint32_t gm2 = relu_bits<H1T>(g2[0]);
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
                 // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
+                VPC_STAMP(4);
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg2[1][H1T];
@@ -290,6 +312,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
                 }
                 // ---------------- dW5~ += dg2 * g1^T   (owner: wave w < 7 -> out tile w; 4 in tiles)
+                VPC_STAMP(5);
                 VPC_CUT();
                 launder(cc, qq);
                 // g1 is RECOMPUTED here (16 MFMAs from z) instead of being kept live since the forward pass: 16 registers
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
                 // ---------------- dg1 = relu'(g1) * (W5~^T dg2)
+                VPC_STAMP(6);
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg1[1][H2T];
@@ -339,6 +363,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64>(W5, mt, dg2[0], cc, qq), gm1, mt);
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
+                VPC_STAMP(7);
                 VPC_CUT();
                 launder(cc, qq);
 #pragma unroll
@@ -363,6 +388,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
                 tile_T_nb<H2T, S4, 1>(W4, 0, dg1, dzt, cc, qq);
             }
+            VPC_STAMP(8);
             // total seeds on the encoder outputs: KL part (parked above) + reparameterisation path
             if (!skip_dec) {
                 const f32x4 dm0 = ld_lat(a.dmean[p], row, ok), dl0 = ld_lat(a.dlogvar[p], row, ok);
@@ -377,6 +403,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             }
         }
     }
+    VPC_STAMP(9);
     // ---- partial block in the layout of the 4-wave kernel (vpc_layout.h): out tile mt of dW6 -> wave mt & 3, regs
     // 28 (mt >> 2) + 4 nt + j;  dW5 tile mt -> wave mt & 3, regs 56 + 16 (mt >> 2) + 4 nt + j;  dW4 tile mt -> wave mt, 88 + j
     float* part = a.part + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
@@ -413,6 +440,12 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
         for (int k = 0; k < DEC8_WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
         a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
     }
+#ifdef VPC_ABLATE
+    VPC_STAMP(10);
+    if (VPC_DBG(64) && blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 3 == 0)
+        printf("dec8 blk %d wave %d: prologue %llu latent %llu g1g2 %llu out %llu w6 %llu dg2 %llu w5 %llu dg1 %llu w4+dz %llu store %llu epi %llu\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10]);
+#endif
 }
 
 size_t dec8_lds(int DT) {
