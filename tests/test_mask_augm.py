@@ -33,7 +33,9 @@ def test_oracle_mask_augm_matches_reference():
     loss, grads, outs = O.torch_reg_step(_params(g, "reg"), L, x, m, mp, _t(g["reg.eps_q"]), _t(g["reg.eps_p"]),
                                          alpha=0.7, beta=0.9, mask_augm=True)
     assert abs(loss.item() - float(g["reg.loss"])) <= 2e-6 * float(g["reg.loss"])
-    assert np.array_equal(outs[4].numpy(), g["reg.mean_q"]) and np.array_equal(outs[2].numpy(), g["reg.x_mean_p"])
+    # same ops on the same inputs: identical up to the host BLAS kernel choice (1 ulp between CPU models)
+    assert np.allclose(outs[4].numpy(), g["reg.mean_q"], rtol=2e-6, atol=1e-7)
+    assert np.allclose(outs[2].numpy(), g["reg.x_mean_p"], rtol=2e-6, atol=1e-7)
     for k in O.PARAM_KEYS:
         assert rel(grads[k].numpy(), g[f"reg.grad.{k}"]) < 5e-6, k
     mf = m * torch.ones(x.shape)

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             VPC_CUT();
             const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
             f32x4 dzt[1] = {zero4()};
+            f32x4 dm0, dl0, lv2, e2;  // pass-end operands, requested before the last wgrad phase (see below)
             if (!skip_dec) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -366,6 +367,11 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_STAMP(7);
                 VPC_CUT();
                 launder(cc, qq);
+                // the parked KL seeds and the inputs of eps * exp(logvar / 2) / 2 come back under this phase's MFMAs
+                dm0 = ld_lat(a.dmean[p], row, ok);
+                dl0 = ld_lat(a.dlogvar[p], row, ok);
+                lv2 = ld_lat(a.logvar[p], row, ok);
+                e2 = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     __syncthreads();
@@ -391,10 +397,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             VPC_STAMP(8);
             // total seeds on the encoder outputs: KL part (parked above) + reparameterisation path
             if (!skip_dec) {
-                const f32x4 dm0 = ld_lat(a.dmean[p], row, ok), dl0 = ld_lat(a.dlogvar[p], row, ok);
                 // eps * exp(logvar / 2) / 2 is re-derived from its inputs here rather than carried through the pass
-                const f32x4 lv2 = ld_lat(a.logvar[p], row, ok);
-                f32x4 e2 = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
                 f32x4 ef;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ef[j] = (4 * q + j < a.L) ? e2[j] * 0.5f * __expf(0.5f * lv2[j]) : 0.f;

@@ -72,6 +72,30 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
     const float* W3 = lds + im.oW3;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
 
+    // PIPE (the vectorised fast path): x is read once per tile (both passes see the same rows, only the mask differs)
+    // and the mask words of the next pass - or x and the mask words of the next tile - are requested before this
+    // pass's MFMAs, with branch-free loads (rows past B read row 0 and are never stored; columns past d are cleared).
+    constexpr bool PIPE = VEC && !AUG;
+    f32x4 xraw[DT];
+    uint32_t mw[DT];
+    const int cq = (4 * q + 3 < a.d) ? 4 * q : 0;
+    auto fetch_x = [&](long r) {
+        const float* xl = a.x + (r < a.B ? r : 0) * a.d + cq;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            xraw[t] = *reinterpret_cast<const f32x4*>(xl + ((t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0));
+    };
+    auto fetch_m = [&](const uint8_t* m, long r) {
+        const uint32_t* ml = reinterpret_cast<const uint32_t*>(m + (r < a.B ? r : 0) * a.d + cq);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) mw[t] = ml[(t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 4 * t : 0];
+    };
+    if (PIPE && (int)blockIdx.x < a.ntiles) {
+        const long r0 = (long)blockIdx.x * TILE_ROWS + w * 16 + c;
+        fetch_x(r0);
+        fetch_m(a.mask[0], r0);
+    }
+
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const long row = (long)tile * TILE_ROWS + w * 16 + c;
         const bool ok = row < a.B;
@@ -82,8 +106,23 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             int cc = c, qq = q;
             launder(cc, qq);
             f32x4 xin[DT];
+            if (PIPE) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
+                for (int t = 0; t < DT; ++t) {
+                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
+                    xin[t] = xraw[t] * mask_to_f32(mw[t] & vm);  // x.float() * mask  (VAE.py:388)
+                }
+                if (p + 1 < a.npass) {
+                    fetch_m(a.mask[p + 1], row);
+                } else if (tile + (int)gridDim.x < a.ntiles) {
+                    const long rn = row + (long)gridDim.x * TILE_ROWS;
+                    fetch_x(rn);
+                    fetch_m(a.mask[0], rn);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
+            }
             VPC_STAMP(1);
             f32x4 h1[H1T];
 #pragma unroll
@@ -150,6 +189,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CH = ENC_CH;
     constexpr int WPC = CH / 16;  // waves per chunk
+    constexpr bool PIPE = VEC && !AUG;
     const EncImg im(DT);
     const int nW = im.total - im.oW2;  // only W2, W3 are needed (layer 1 has no dgrad)
     load_image(lds, a.img + im.oW2, nW);
@@ -178,17 +218,30 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
         for (int p = 0; p < a.npass; ++p) {
             int cc = c, qq = q;
             launder(cc, qq);
+            // PIPE (the vectorised fast path): every global operand of the pass is requested one phase before it is
+            // needed, with branch-free loads (row clamped to 0 for rows past B; only the seeds dml are masked - zero
+            // seeds make dh2, dh1 and every wgrad contribution of such a row exactly zero, whatever h1 / h2 / x hold).
+            // hipcc turns `ok ? load : 0` into an exec-masked branch with an s_waitcnt vmcnt(0) at the join, and a
+            // load issued at its point of use leaves all 8 waves (barrier-synchronised) waiting on HBM together.
+            const long rowc = ok ? row : 0;
             f32x4 dml[2];
             if (a.lp == 16) {
-                dml[0] = ld_tile<true>(a.dmean[p], row, 16, 4 * q, 16, ok);
-                dml[1] = ld_tile<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok);
+                dml[0] = PIPE ? ld_tile_o<true>(a.dmean[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dmean[p], row, 16, 4 * q, 16, ok);
+                dml[1] = PIPE ? ld_tile_o<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok);
             } else {
                 dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
                 dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
             }
-            f32x4 h2[H2T];
+            f32x4 h2[H2T], h1[H1T];
+            if (PIPE) {
 #pragma unroll
-            for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
+                for (int t = 0; t < H2T; ++t) h2[t] = *reinterpret_cast<const f32x4*>(a.h2[p] + rowc * H2P + 16 * t + 4 * q);
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) h1[t] = *reinterpret_cast<const f32x4*>(a.h1[p] + rowc * H1P + 16 * t + 4 * q);
+            } else {
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
+            }
             // ---- dW3~ += dml * h2^T   (owner: wave w -> out tile w>>2, in tile w&3)
             for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
                 __syncthreads();
@@ -212,9 +265,25 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             f32x4 dh2[H2T];
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
-            f32x4 h1[H1T];
+            if (!PIPE) {
 #pragma unroll
-            for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
+                for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
+            }
+            // x and mask words for the layer-1 wgrad, two phases ahead
+            f32x4 xraw[DT];
+            uint32_t mw[DT];
+            if (PIPE) {
+                const long ro = rowc * a.d + ((4 * q + 3 < a.d) ? 4 * q : 0);
+                const float* xl = a.x + ro;
+                const uint32_t* ml = reinterpret_cast<const uint32_t*>(a.mask[p] + ro);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    // d > 16 * DT / 2 (dt_for): the first DT / 2 tiles hold no out-of-range columns
+                    const int fo = (t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0;
+                    xraw[t] = *reinterpret_cast<const f32x4*>(xl + fo);
+                    mw[t] = ml[fo >> 2];
+                }
+            }
             // ---- dW2~ += dh2 * h1^T   (owner: wave w<7 -> in tile w, all 4 out tiles)
             launder(cc, qq);
             for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
@@ -266,8 +335,16 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 }
             }
             f32x4 xin[DT];
+            if (PIPE) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
+                for (int t = 0; t < DT; ++t) {
+                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
+                    xin[t] = xraw[t] * mask_to_f32(mw[t] & vm);  // out-of-range columns: weight gradient stays 0
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
+            }
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles)
             launder(cc, qq);
             for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
