@@ -49,7 +49,7 @@ def measured_traffic(B, d, L):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         if (B, d, L) == (65536, 128, 10):
-            return t["kernels"]["dec_kernel<8,true,1>"]["hbm_bytes_corrected"]
+            return t["kernels"]["dec8_kernel<8,true>"]["hbm_bytes_corrected"]
     except Exception:
         pass
     return None
@@ -174,7 +174,7 @@ def main():
         "config": {"workload": f"Reg_VAE kl_reg alpha=1 beta=1 training step, synthetic tabular B={B} per GPU, "
                                f"d={d}, L={Ld}, MCAR mask 0.7, p_missingness=30, Adam lr=1e-3",
                    "global_batch": world * B, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "vpc::dec_kernel<8,true,1> (vpc_decoder_fused)",
+        "roofline": {"bound": "mfma", "kernel": "vpc::dec8_kernel<8,true> (vpc_decoder_fused)",
                      "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(B, d, Ld),
                      "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},

@@ -276,7 +276,7 @@ def test_api_path_training_with_torch_adam_matches_golden():
 
 
 # ----------------------------------------------------------------------------------------------- sizes / edges
-@pytest.mark.parametrize("d,B", [(13, 5), (40, 129), (128, 1), (100, 300), (128, 1000)])
+@pytest.mark.parametrize("d,B", [(13, 5), (40, 129), (128, 1), (100, 300), (128, 1000), (125, 70), (72, 130), (66, 257)])
 def test_fused_step_ragged_shapes_vs_oracle(d, B):
     params = O.init_params(d, L, seed=7)
     x, mask, mask_p, eq, ep = synth(B, d, seed=B + d)
@@ -290,6 +290,22 @@ def test_fused_step_ragged_shapes_vs_oracle(d, B):
     for k, p in zip(O.PARAM_KEYS, m.trainable()):
         assert rel(flat[off:off + p.numel()].reshape(p.shape), grads_ref[k].numpy()) < 2e-4, k
         off += p.numel()
+
+
+@pytest.mark.parametrize("d,B", [(128, 300), (100, 130), (125, 70)])
+def test_decoder_kernel_variants_agree(d, B, monkeypatch):
+    """d in (64, 128] has two fused decoder kernels (8 waves x 1 row tile - the default - and 4 waves x 2 row tiles,
+    VPC_DEC8=0): same arguments, same partial-block layout, results equal up to fp32 summation order."""
+    params = O.init_params(d, L, seed=11)
+    x, mask, mask_p, eq, ep = synth(B, d, seed=B * 3 + d)
+    res = []
+    for v in ("1", "0"):
+        monkeypatch.setenv("VPC_DEC8", v)
+        tr = vpc.FusedTrainer(make_model(vpc.Reg_VAE, d, params))
+        tr.step(x.to(DEV), mask.to(DEV), mask_p.to(DEV), eq.to(DEV), ep.to(DEV), alpha=0.6, beta=0.9, update=False)
+        res.append((tr.loss_value(), tr.grad.cpu().numpy().copy()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])
+    assert rel(res[0][1], res[1][1]) < 2e-5
 
 
 def test_full_size_step_vs_oracle_and_api_path():

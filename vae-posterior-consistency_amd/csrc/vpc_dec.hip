@@ -575,8 +575,9 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     }
     if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
     if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
-    // experiment switch: the 8-wave / one-tile-per-wave variant (vpc_dec8.hip), d in (64, 128] only
-    static const bool use8 = [] { const char* e = getenv("VPC_DEC8"); return e && atoi(e) != 0; }();
-    if (use8 && dt_for(d) == 8) return dec8_dispatch(a, vec, (hipStream_t)stream);
+    // d in (64, 128]: the 8-wave / one-tile-per-wave kernel (vpc_dec8.hip); VPC_DEC8=0 selects the 4-wave / two-tiles-
+    // per-wave kernel of this file instead (same arguments, same partial-block layout; kept for A/B runs and for d <= 64)
+    const char* e8 = getenv("VPC_DEC8");
+    if (dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, (hipStream_t)stream);
     return dispatch<MODE_FUSED>(a, vec, (hipStream_t)stream);
 }
