@@ -112,74 +112,34 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             asm volatile("" ::: "memory");  // keep LDS weight reads inside the pass (see vpc_enc.hip)
             int cc = c, qq = q;
             launder(cc, qq);
-            // ---------------- latent: z = mean + eps * exp(logvar / 2), KL terms and their seeds
-            f32x4 z[1][1], dmu_kl, dlv_kl;
+            // ---------------- latent: z = mean + eps * exp(logvar / 2).  The KL terms and their seeds are computed at the END
+            // of the pass from a second read of the (L2-resident) statistics: nothing of them is live - or parked in
+            // memory - while the decoder runs (this kernel has 256 registers per wave)
+            const bool two = a.npass == 2;
+            f32x4 z[1][1];
             {
-                const bool two = a.npass == 2;
                 const f32x4 mu = ld_lat(a.mean[p], row, ok);
                 const f32x4 lv = ld_lat(a.logvar[p], row, ok);
-                f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
-                const uint32_t has_o = opaque_mask(two);
-                const f32x4 mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row, ok), has_o);
-                const f32x4 lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row, ok), has_o);
+                const f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sig = __expf(0.5f * lv[j]);
-                    z[0][0][j] = mu[j] + e[j] * sig;
-                }
-                const float b0 = (p == 0) ? a.bq : a.bp;
-                const float sgn = (p == 0) ? 1.f : -1.f;
-                const float crr = two ? a.cr : 0.f;
-                float kl0 = 0.f, klr = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float elv = __expf(lv[j]);
-                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
-                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
-                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
-                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
-                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
-                    const float dl = b0 * 0.5f * (elv - 1.f) +
-                                     crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
-                    dmu_kl[j] = dm * a.inv_B;
-                    dlv_kl[j] = dl * a.inv_B;
-                }
-                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
-                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
-                    f32x4 e3 = ld_lat(a.eps_ml, row, ok);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) e3[j] = (4 * q + j < a.L) ? e3[j] : 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool live = ok && 4 * q + j < a.L;
-                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
-                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
-                        const float dlt = mq + e3[j] * sq - mp;
-                        const float g = a.wml * dlt * eip * a.inv_B;
-                        if (p == 0) {
-                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
-                            dmu_kl[j] += g;
-                            dlv_kl[j] += g * e3[j] * 0.5f * sq;
-                        } else {
-                            dmu_kl[j] -= g;
-                            dlv_kl[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
-                        }
-                    }
-                }
+                for (int j = 0; j < 4; ++j)  // padded eps rows hold noise
+                    z[0][0][j] = mu[j] + ((4 * q + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
             }
-            // the KL seeds are parked in the output arrays now and picked up again when dz is known: 8 registers that
-            // would otherwise be live across the whole pass (this kernel has 256 per wave)
-            st_lat(a.dmean[p], row, ok, dmu_kl);
-            st_lat(a.dlogvar[p], row, ok, dlv_kl);
+            f32x4 mu, lv, e, mo, lo, e3;  // pass-end operands
+            auto fetch_stats = [&]() {
+                mu = ld_lat(a.mean[p], row, ok);
+                lv = ld_lat(a.logvar[p], row, ok);
+                e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
+                const uint32_t has_o = opaque_mask(two);
+                mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row, ok), has_o);
+                lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row, ok), has_o);
+                e3 = and4(ld_lat(a.eps_ml ? a.eps_ml : a.mean[p], row, ok), opaque_mask(a.eps_ml != nullptr));
+            };
             VPC_STAMP(1);
             VPC_CUT();
             const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
             f32x4 dzt[1] = {zero4()};
-            f32x4 dm0, dl0, lv2, e2;  // pass-end operands, requested before the last wgrad phase (see below)
+            if (skip_dec) fetch_stats();
             if (!skip_dec) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -367,11 +327,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_STAMP(7);
                 VPC_CUT();
                 launder(cc, qq);
-                // the parked KL seeds and the inputs of eps * exp(logvar / 2) / 2 come back under this phase's MFMAs
-                dm0 = ld_lat(a.dmean[p], row, ok);
-                dl0 = ld_lat(a.dlogvar[p], row, ok);
-                lv2 = ld_lat(a.logvar[p], row, ok);
-                e2 = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
+                fetch_stats();  // the pass-end operands come in under this phase's MFMAs
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     __syncthreads();
@@ -395,14 +351,58 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 tile_T_nb<H2T, S4, 1>(W4, 0, dg1, dzt, cc, qq);
             }
             VPC_STAMP(8);
-            // total seeds on the encoder outputs: KL part (parked above) + reparameterisation path
-            if (!skip_dec) {
-                // eps * exp(logvar / 2) / 2 is re-derived from its inputs here rather than carried through the pass
-                f32x4 ef;
+            // ---------------- KL terms, their seeds, and the total seeds on the encoder outputs (KL part + reparameterisation)
+            {
+                f32x4 dmu_kl, dlv_kl;
+                const float b0 = (p == 0) ? a.bq : a.bp;
+                const float sgn = (p == 0) ? 1.f : -1.f;
+                const float crr = two ? a.cr : 0.f;
+                float kl0 = 0.f, klr = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ef[j] = (4 * q + j < a.L) ? e2[j] * 0.5f * __expf(0.5f * lv2[j]) : 0.f;
-                st_lat(a.dmean[p], row, ok, dm0 + dzt[0]);
-                st_lat(a.dlogvar[p], row, ok, dl0 + dzt[0] * ef);
+                for (int j = 0; j < 4; ++j) {
+                    const float elv = __expf(lv[j]);
+                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
+                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
+                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
+                    const float dl = b0 * 0.5f * (elv - 1.f) +
+                                     crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
+                    dmu_kl[j] = dm * a.inv_B;
+                    dlv_kl[j] = dl * a.inv_B;
+                }
+                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
+                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = ok && 4 * q + j < a.L;
+                        const float e3j = (4 * q + j < a.L) ? e3[j] : 0.f;
+                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
+                        const float dlt = mq + e3j * sq - mp;
+                        const float g = a.wml * dlt * eip * a.inv_B;
+                        if (p == 0) {
+                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                            dmu_kl[j] += g;
+                            dlv_kl[j] += g * e3j * 0.5f * sq;
+                        } else {
+                            dmu_kl[j] -= g;
+                            dlv_kl[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
+                        }
+                    }
+                }
+                if (skip_dec) {
+                    st_lat(a.dmean[p], row, ok, dmu_kl);
+                    st_lat(a.dlogvar[p], row, ok, dlv_kl);
+                } else {
+                    f32x4 ef;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ef[j] = (4 * q + j < a.L) ? e[j] * 0.5f * __expf(0.5f * lv[j]) : 0.f;
+                    st_lat(a.dmean[p], row, ok, dmu_kl + dzt[0]);
+                    st_lat(a.dlogvar[p], row, ok, dlv_kl + dzt[0] * ef);
+                }
             }
         }
     }
