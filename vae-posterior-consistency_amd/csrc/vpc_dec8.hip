@@ -20,6 +20,12 @@ constexpr int DEC8_WAVES = 8, DEC8_THREADS = 512;
 
 // Single-chain tile products with a 2-deep fragment pipeline: the second wave of the SIMD hides LDS latency here, so
 // only two A fragments are in flight (8 registers) instead of the whole tile's (up to 32) as in the 4-wave kernel.
+#ifdef VPC_ABLATE
+#define ABL(bit) VPC_DBG(bit)   // timing experiments (diagnostic build): 1 no staging writes, 2 no barriers, 4 no wgrad MFMAs
+#else
+#define ABL(bit) false
+#endif
+
 template <int KT, int S>
 __device__ __forceinline__ f32x4 tile_fwd_p2(const float* W, int mt, const f32x4 (&in)[KT], int m, int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
@@ -236,15 +242,15 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    __syncthreads();
-                    if (round_w == r) {
+                    if (!ABL(2)) __syncthreads();
+                    if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[0][t], sb);
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[0][t], sb);
                     }
-                    __syncthreads();
-                    if (own6) {
+                    if (!ABL(2)) __syncthreads();
+                    if (own6 && !ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -287,15 +293,15 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 const uint32_t gm1 = relu_bits<H2T>(g1b[0]);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    __syncthreads();
-                    if (round_w == r) {
+                    if (!ABL(2)) __syncthreads();
+                    if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[0][t], sb);
 #pragma unroll
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1b[0][t], sb);
                     }
-                    __syncthreads();
-                    if (own5) {
+                    if (!ABL(2)) __syncthreads();
+                    if (own5 && !ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -330,14 +336,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 fetch_stats();  // the pass-end operands come in under this phase's MFMAs
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    __syncthreads();
-                    if (round_w == r) {
+                    if (!ABL(2)) __syncthreads();
+                    if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[0][t], sb);
                         stage_write_b<CH>(stB, 0, z[0][0], sb);
                     }
-                    __syncthreads();
-                    if (own4) {
+                    if (!ABL(2)) __syncthreads();
+                    if (own4 && !ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
