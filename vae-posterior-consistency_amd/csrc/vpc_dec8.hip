@@ -172,7 +172,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 f32x4 dpre[1][DT];
                 float sa = 0.f, se = 0.f;
                 const bool hasB = a.mB[p] != nullptr;
-                const float hasBf = hasB ? 1.f : 0.f;
+                const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
                 const float* xl;
                 const uint32_t* mal;
                 const uint32_t* mbl;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     } else {
                         xv = ld_tile<false>(a.x, row, a.d, f0, a.d, ok);
                         ua = ld_mask_raw<false>(a.mA[p], row, a.d, f0, a.d, ok);
-                        ub = hasB ? ld_mask_raw<false>(a.mB[p], row, a.d, f0, a.d, ok) : 0u;
+                        ub = hasB ? ld_mask_raw<false>(a.mB[p], row, a.d, f0, a.d, ok) : ua;
                     }
                 };
                 f32x4 xv_n;
@@ -217,16 +217,19 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         ub &= vm;
                     }
                     const f32x4 mA = mask_to_f32(ua);
-                    const f32x4 mE = mA * (1.f - mask_to_f32(ub)) * hasBf;
+                    // without a second mask the B words alias the A words (fetch): mA (1 - mA) = 0, no extra factor needed
+                    const f32x4 mE = mA * (1.f - mask_to_f32(ub));
+                    // every VALU instruction here costs MFMA time (fp32 MFMA and VALU do not overlap on a SIMD, see
+                    // tools/microbench/mfma_valu_overlap.hip): constants are folded per pass, not per element
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xh = fast_sigmoid(pre[0][j]);
                         const float diff = xh - xv[j];
-                        const float t = half_lv + 0.5f * diff * diff * inv_s2;
-                        sa += mA[j] * t;
-                        se += mE[j] * t;
-                        const float dxh = (a.cA[p] * mA[j] + a.cE[p] * mE[j]) * diff * inv_s2 * a.inv_B;
-                        dpre[0][mt][j] = dxh * xh * (1.f - xh);
+                        const float t = __builtin_fmaf(diff * diff, hinv_s2, half_lv);
+                        sa = __builtin_fmaf(mA[j], t, sa);
+                        se = __builtin_fmaf(mE[j], t, se);
+                        const float wgt = __builtin_fmaf(kE, mE[j], kA * mA[j]);  // (cA mA + cE mE) / (sigma^2 B)
+                        dpre[0][mt][j] = (wgt * diff) * __builtin_fmaf(-xh, xh, xh);
                     }
                     // pin this tile's VALU here: without a volatile use hipcc sinks the sigmoid / loss code of ALL tiles
                     // below the loop (next to the first use of dpre), keeping 8 tiles of pre / x / masks live
