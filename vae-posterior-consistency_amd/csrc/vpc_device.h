@@ -144,25 +144,28 @@ __device__ __forceinline__ void stage_write(float* st, int t, f32x4 v, int colba
 // stage_write with the lane-dependent part of the address precomputed (sb[j] = element offset of feature 4q+j in
 // tile 0): the tile index t only adds the compile-time constant 16 * t * CH, which folds into the ds_write immediate
 // offset - no address VALU per write (the plain form costs ~3 VALU per ds_write_b32, 60 writes per staging round).
+// the XOR term uses at most the low 4 bits of the row (f & 15 = 4 q + j: it must not depend on the tile index), which
+// is enough to spread a wave's 16 rows over 16 different 16-byte slots for any CH >= 64
+template <int CH>
+__device__ __forceinline__ constexpr int stage_swz_mask() { return CH / 4 - 1 < 15 ? CH / 4 - 1 : 15; }
 template <int CH>
 __device__ __forceinline__ void stage_bases(int (&sb)[4], int colbase, int c, int q) {
     const int col = colbase + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = 4 * q + j;
-        sb[j] = f * CH + ((((col >> 2) ^ (f & (CH / 4 - 1))) << 2) | (col & 3));
+        sb[j] = f * CH + ((((col >> 2) ^ (f & stage_swz_mask<CH>())) << 2) | (col & 3));
     }
 }
 template <int CH>
 __device__ __forceinline__ void stage_write_b(float* st, int t, f32x4 v, const int (&sb)[4]) {
-    static_assert(CH / 4 - 1 <= 15, "the swizzle term must not depend on the tile index");
 #pragma unroll
     for (int j = 0; j < 4; ++j) st[16 * t * CH + sb[j]] = v[j];
 }
 template <int CH>
 __device__ __forceinline__ f32x4 stage_frag(const float* st, int t, int s, int m, int q) {
     const int f = 16 * t + m;
-    return *reinterpret_cast<const f32x4*>(st + f * CH + 4 * ((4 * s + q) ^ (f & (CH / 4 - 1))));
+    return *reinterpret_cast<const f32x4*>(st + f * CH + 4 * ((4 * s + q) ^ (f & stage_swz_mask<CH>())));
 }
 
 // ---- row-major [rows][ld] global <-> C-layout tile.  Loads are branch-free: an out-of-range element reads

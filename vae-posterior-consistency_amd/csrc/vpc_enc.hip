@@ -179,32 +179,42 @@ struct EncBwdArgs {
     const float* dlogvar[2];
     float* part;
     long B;
-    int d, L, npass, ntiles, lp;
+    int d, L, npass, ntiles, lp, dbg;
 };
 
-constexpr int ENC_CH = 64;  // batch rows per wgrad staging chunk
+#ifdef VPC_ABLATE
+#define ABLE(bit) ((a.dbg & (bit)) != 0)  // timing experiments (diagnostic build): 1 no staging writes, 2 no barriers, 4 no wgrad 1/2 MFMAs
+#else
+#define ABLE(bit) false
+#endif
 
 template <int DT, bool VEC, bool AUG>
 __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CH = ENC_CH;
-    constexpr int WPC = CH / 16;  // waves per chunk
+#ifdef VPC_ABLATE
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    // Staging is full width (all 128 batch rows of the workgroup tile at once): ONE write + barrier + read round per
+    // wgrad, 6 barriers per pass instead of 12 (barriers were 16 % of this kernel, `profiles/r01_notes.md`).  That
+    // fits in LDS because the B operand of the layer-1 wgrad - x * mask, the only use of x in this kernel - never
+    // goes through LDS: a B fragment wants batch rows along the register index and features along the lanes, which
+    // is how row-major x lies in memory, so the tile's owner wave reads it from global memory directly.
+    constexpr int CH = TILE_ROWS;
     constexpr bool PIPE = VEC && !AUG;
     const EncImg im(DT);
     const int nW = im.total - im.oW2;  // only W2, W3 are needed (layer 1 has no dgrad)
     load_image(lds, a.img + im.oW2, nW);
     float* W2 = lds;
     float* W3 = lds + (im.oW3 - im.oW2);
-    float* stA = lds + nW;             // [112][CH]
-    float* stB = stA + H1P * CH;       // [16*DT or 112][CH]
-    constexpr int NB = (16 * DT > H1P ? 16 * DT : H1P);
-    float* db1s = stB + NB * CH;       // [WAVES][128]: per-wave bias-gradient sums (no atomics: bit-reproducible)
+    float* stA = lds + nW;             // [112][CH]  dY operands (dml, dh2, dh1)
+    float* stB = stA + H1P * CH;       // [112][CH]  activations (h2, h1)
+    float* db1s = stB + H1P * CH;      // [WAVES][128]: per-wave bias-gradient sums (no atomics across waves: bit-reproducible)
     for (int i = threadIdx.x; i < WAVES * 128; i += THREADS) db1s[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
-    const int colbase = 16 * (w % WPC);
     int sb[4];  // per-lane element offsets of the staging writes (tile 0); tiles add a compile-time constant
-    stage_bases<CH>(sb, colbase, c, q);
+    stage_bases<CH>(sb, 16 * w, c, q);
 
     f32x4 acc1[H1T], acc2[H2T], acc3 = zero4();
 #pragma unroll
@@ -212,19 +222,51 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < H2T; ++i) acc2[i] = zero4();
 
+    // layer-1 input feature of this lane as a B-fragment column (owner: wave w < DT -> input tile w)
+    const int fB = 16 * w + c;
+    const int din = AUG ? 2 * a.d : a.d;
+    const bool fx = fB < a.d, fm = AUG && fB >= a.d && fB < din;        // x * mask column / appended mask column
+    const int colB = fx ? fB : (fm ? fB - a.d : 0);
+
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long row = (long)tile * TILE_ROWS + w * 16 + c;
+        const long row0 = (long)tile * TILE_ROWS;
+        const long row = row0 + w * 16 + c;
         const bool ok = row < a.B;
         for (int p = 0; p < a.npass; ++p) {
             int cc = c, qq = q;
             launder(cc, qq);
-            // PIPE (the vectorised fast path): every global operand of the pass is requested one phase before it is
-            // needed, with branch-free loads (row clamped to 0 for rows past B; only the seeds dml are masked - zero
-            // seeds make dh2, dh1 and every wgrad contribution of such a row exactly zero, whatever h1 / h2 / x hold).
-            // hipcc turns `ok ? load : 0` into an exec-masked branch with an s_waitcnt vmcnt(0) at the join, and a
-            // load issued at its point of use leaves all 8 waves (barrier-synchronised) waiting on HBM together.
+            VPC_STAMP(0);
+            // B fragments of slice s (batch rows row0 + 16 s + 4 q + j): raw x and mask bytes; rows past B read row 0
+            // (their dh1 is exactly zero), columns past the input width are cleared when the fragment is formed
+            // 32-bit offsets from a per-tile (uniform) base, formed from the laundered lane id when a slice is
+            // requested: hipcc otherwise precomputes all 32 64-bit row addresses per tile and spills them
+            const float* xt = a.x + row0 * a.d;
+            const uint8_t* mt = a.mask[p] + row0 * a.d;
+            const long lastrow = a.B - 1 - row0;
+            const unsigned lim = (unsigned)(lastrow < TILE_ROWS - 1 ? lastrow : TILE_ROWS - 1);
+            auto ld_xb = [&](int sl, f32x4& xv, uint32_t& mb) {
+                mb = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned lr = 16u * sl + 4u * (unsigned)qq + j;
+                    lr = lr < lim ? lr : lim;
+                    const unsigned o = lr * (unsigned)a.d + (unsigned)colB;
+                    xv[j] = xt[o];
+                    mb |= (uint32_t)mt[o] << (8 * j);
+                }
+            };
+            auto mk_fb = [&](const f32x4& xv, uint32_t mb) -> f32x4 {
+                const f32x4 m = mask_to_f32(mb);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fx ? xv[j] * m[j] : (fm ? m[j] : 0.f);
+                return v;
+            };
+            // PIPE (the vectorised fast path): branch-free loads - rows past B read row 0 and only the seeds dml are
+            // masked: zero seeds make dh2, dh1 and every wgrad contribution of such a row exactly zero, whatever h1 /
+            // h2 / x hold.  (hipcc turns `ok ? load : 0` into an exec-masked branch with a vmcnt(0) wait at the join.)
             const long rowc = ok ? row : 0;
-            f32x4 dml[2];
+            f32x4 dml[2], h2[H2T], h1[H1T];
             if (a.lp == 16) {
                 dml[0] = PIPE ? ld_tile_o<true>(a.dmean[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dmean[p], row, 16, 4 * q, 16, ok);
                 dml[1] = PIPE ? ld_tile_o<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok);
@@ -232,7 +274,6 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
                 dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
             }
-            f32x4 h2[H2T], h1[H1T];
             if (PIPE) {
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) h2[t] = *reinterpret_cast<const f32x4*>(a.h2[p] + rowc * H2P + 16 * t + 4 * q);
@@ -241,77 +282,68 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             } else {
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
             }
             // ---- dW3~ += dml * h2^T   (owner: wave w -> out tile w>>2, in tile w&3)
-            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
-                __syncthreads();
-                if (w / WPC == ch) {
-                    stage_write_b<CH>(stA, 0, dml[0], sb);
-                    stage_write_b<CH>(stA, 1, dml[1], sb);
+            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(1)) {
+                stage_write_b<CH>(stA, 0, dml[0], sb);
+                stage_write_b<CH>(stA, 1, dml[1], sb);
 #pragma unroll
-                    for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int s = 0; s < WPC; ++s) {
-                    const f32x4 fa = stage_frag<CH>(stA, w >> 2, s, cc, qq);
-                    const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
-                }
+                for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
             }
+            if (!ABLE(2)) __syncthreads();
+#pragma unroll
+            for (int s = 0; s < CH / 16; ++s) {
+                const f32x4 fa = stage_frag<CH>(stA, w >> 2, s, cc, qq);
+                const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
+            }
+            VPC_STAMP(1);
             // ---- dh2 = relu'(h2) * (W3~^T dml)
             launder(cc, qq);
             f32x4 dh2[H2T];
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
-            if (!PIPE) {
-#pragma unroll
-                for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
-            }
-            // x and mask words for the layer-1 wgrad, two phases ahead
-            f32x4 xraw[DT];
-            uint32_t mw[DT];
-            if (PIPE) {
-                const long ro = rowc * a.d + ((4 * q + 3 < a.d) ? 4 * q : 0);
-                const float* xl = a.x + ro;
-                const uint32_t* ml = reinterpret_cast<const uint32_t*>(a.mask[p] + ro);
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    // d > 16 * DT / 2 (dt_for): the first DT / 2 tiles hold no out-of-range columns
-                    const int fo = (t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0;
-                    xraw[t] = *reinterpret_cast<const f32x4*>(xl + fo);
-                    mw[t] = ml[fo >> 2];
-                }
-            }
+            VPC_STAMP(2);
             // ---- dW2~ += dh2 * h1^T   (owner: wave w<7 -> in tile w, all 4 out tiles)
             launder(cc, qq);
-            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
-                __syncthreads();
-                if (w / WPC == ch) {
+            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(1)) {
 #pragma unroll
-                    for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dh2[t], sb);
+                for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dh2[t], sb);
 #pragma unroll
-                    for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, h1[t], sb);
-                }
-                __syncthreads();
-                if (w < H1T) {
+                for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, h1[t], sb);
+            }
+            if (!ABLE(2)) __syncthreads();
+            if (w < H1T && !ABLE(4)) {
 #pragma unroll
-                    for (int s = 0; s < WPC; ++s) {
-                        const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
-                        // A fragments double-buffered by hand (hipcc sinks each LDS read to its first use: one exposed
-                        // LDS latency per 4 MFMAs); the sched_barrier pins the read of mt+1 above the MFMAs of mt
-                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
+                for (int s = 0; s < CH / 16; ++s) {
+                    asm volatile("" ::: "memory");
+                    const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
+                    // A fragments double-buffered by hand (hipcc sinks each LDS read to its first use: one exposed
+                    // LDS latency per 4 MFMAs); the sched_barrier pins the read of mt+1 above the MFMAs of mt
+                    f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
 #pragma unroll
-                        for (int mt = 0; mt < H2T; ++mt) {
-                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H2T ? mt + 1 : mt, s, cc, qq);
-                            __builtin_amdgcn_sched_barrier(0);
+                    for (int mt = 0; mt < H2T; ++mt) {
+                        const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H2T ? mt + 1 : mt, s, cc, qq);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc2[mt] = VPC_MFMA(fa[j], fb[j], acc2[mt]);
-                            fa = fn;
-                        }
+                        for (int j = 0; j < 4; ++j) acc2[mt] = VPC_MFMA(fa[j], fb[j], acc2[mt]);
+                        fa = fn;
                     }
                 }
+            }
+            VPC_STAMP(3);
+            // the first two B slices of the layer-1 wgrad come in under the dh1 MFMAs
+            constexpr int NS = CH / 16;
+            f32x4 xb[3];  // rotating: slices s, s + 1, s + 2
+            uint32_t mbb[3];
+            if (w < DT) {
+                ld_xb(0, xb[0], mbb[0]);
+                ld_xb(1, xb[1], mbb[1]);
             }
             // ---- dh1 = relu'(h1) * (W2~^T dh2);  db1 += dh1
             launder(cc, qq);
@@ -334,44 +366,33 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                     if (c == 0) atomicAdd(&db1s[w * 128 + 16 * mt + 4 * q + j], v);
                 }
             }
-            f32x4 xin[DT];
-            if (PIPE) {
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
-                    xin[t] = xraw[t] * mask_to_f32(mw[t] & vm);  // out-of-range columns: weight gradient stays 0
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
-            }
-            // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles)
+            VPC_STAMP(4);
+            // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles; B straight from global)
             launder(cc, qq);
-            for (int ch = 0; ch < TILE_ROWS / CH; ++ch) {
-                __syncthreads();
-                if (w / WPC == ch) {
+            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(1)) {
 #pragma unroll
-                    for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
+                for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
+            }
+            if (!ABLE(2)) __syncthreads();
+            if (w < DT && !ABLE(4)) {
 #pragma unroll
-                    for (int t = 0; t < DT; ++t) stage_write_b<CH>(stB, t, xin[t], sb);
-                }
-                __syncthreads();
-                if (w < DT) {
+                for (int s = 0; s < NS; ++s) {
+                    asm volatile("" ::: "memory");  // keep each slice's loads in its slice (hipcc hoists all 8 otherwise)
+                    if (s + 2 < NS) ld_xb(s + 2, xb[(s + 2) % 3], mbb[(s + 2) % 3]);
+                    const f32x4 fb = mk_fb(xb[s % 3], mbb[s % 3]);
+                    f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
 #pragma unroll
-                    for (int s = 0; s < WPC; ++s) {
-                        const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
-                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
+                    for (int mt = 0; mt < H1T; ++mt) {
+                        const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H1T ? mt + 1 : mt, s, cc, qq);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int mt = 0; mt < H1T; ++mt) {
-                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H1T ? mt + 1 : mt, s, cc, qq);
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc1[mt] = VPC_MFMA(fa[j], fb[j], acc1[mt]);
-                            fa = fn;
-                        }
+                        for (int j = 0; j < 4; ++j) acc1[mt] = VPC_MFMA(fa[j], fb[j], acc1[mt]);
+                        fa = fn;
                     }
                 }
             }
+            VPC_STAMP(5);
         }
     }
     // ---- write this workgroup's gradient partial block
@@ -398,8 +419,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 static size_t enc_fwd_lds(int DT) { return sizeof(float) * EncImg(DT).total; }
 static size_t enc_bwd_lds(int DT) {
     const EncImg im(DT);
-    const int nb = 16 * DT > H1P ? 16 * DT : H1P;
-    return sizeof(float) * ((im.total - im.oW2) + H1P * ENC_CH + nb * ENC_CH + WAVES * 128);
+    return sizeof(float) * ((im.total - im.oW2) + 2 * H1P * TILE_ROWS + WAVES * 128);
 }
 
 template <typename K, typename A>
@@ -457,6 +477,9 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
     if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     EncBwdArgs a{};
     a.x = x; a.img = enc_img; a.part = partials; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
+#ifdef VPC_ABLATE
+    if (const char* e = getenv("VPC_DEBUG_ENC")) a.dbg = atoi(e);
+#endif
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
