@@ -69,9 +69,11 @@ def test_encoder_decoder_forward_vs_oracle(d, B):
     P = O._np(params)
     c = O.closed_form_pass(P, x.numpy().astype(np.float64), mask.numpy().astype(np.float64),
                            eq.numpy().astype(np.float64), L)
-    assert np.allclose(h1.cpu().numpy()[:, :100], c.h1, atol=2e-5)
-    assert np.allclose(h1.cpu().numpy()[:, 100], 1.0) and np.all(h1.cpu().numpy()[:, 101:] == 0)
-    assert np.allclose(h2.cpu().numpy()[:, :50], c.h2, atol=2e-5) and np.allclose(h2.cpu().numpy()[:, 50], 1.0)
+    from vpc_amd._lib import HIDDEN_POS1 as P1, HIDDEN_POS2 as P2  # unit -> position in the padded workspace
+    h1n, h2n = h1.cpu().numpy(), h2.cpu().numpy()
+    assert np.allclose(h1n[:, P1[:100]], c.h1, atol=2e-5)
+    assert np.allclose(h1n[:, P1[100]], 1.0) and np.all(np.delete(h1n, P1, axis=1) == 0)
+    assert np.allclose(h2n[:, P2[:50]], c.h2, atol=2e-5) and np.allclose(h2n[:, P2[50]], 1.0)
     xh = torch.empty(B, d, device=DEV)
     vpc.ops.decoder_fwd(z, m._dec_img(), xh, d, L)
     assert torch.allclose(xh.cpu(), xh_ref, atol=2e-5)

@@ -101,24 +101,25 @@ def test_packed_chain_matches_oracle(d, Ld):
 
     def fwd(mask, eps):
         xin = np.zeros((B, S1)); xin[:, :d] = x * mask
-        h1 = np.maximum(xin @ W1.T + b1[:112], 0)            # [B,112], h1[:,100] == 1
+        h1 = np.maximum(xin @ W1.T + b1[:112], 0)            # [B,112], constant unit == 1
         h1p = np.zeros((B, 128)); h1p[:, :112] = h1
-        h2 = np.maximum(h1p @ W2.T, 0)                       # [B,64],  h2[:,50] == 1
+        h2 = np.maximum(h1p @ W2.T, 0)                       # [B,64],  constant unit == 1
         o = h2 @ W3.T                                        # [B,32]   mean tile | logvar tile
         mu, lv = o[:, :Ld], o[:, 16:16 + Ld]
         z = np.zeros((B, 64)); z[:, :Ld] = mu + eps * np.exp(lv / 2); z[:, Ld] = 1.0
-        g1 = np.maximum(z @ W4.T, 0)                         # [B,64],  g1[:,50] == 1
-        g2 = np.maximum(g1 @ W5.T, 0)                        # [B,112], g2[:,100] == 1
+        g1 = np.maximum(z @ W4.T, 0)                         # [B,64],  constant unit == 1
+        g2 = np.maximum(g1 @ W5.T, 0)                        # [B,112], constant unit == 1
         g2p = np.zeros((B, 128)); g2p[:, :112] = g2
         xh = 1 / (1 + np.exp(-(g2p @ W6.T)))                 # [B,16*DT]
         return dict(xin=xin, h1=h1, h1p=h1p, h2=h2, o=o, mu=mu, lv=lv, z=z, g1=g1, g2=g2, g2p=g2p, xh=xh)
 
     fq = fwd(m, eq)
-    assert np.allclose(fq["h1"][:, 100], 1) and np.allclose(fq["h2"][:, 50], 1)
-    assert np.allclose(fq["g1"][:, 50], 1) and np.allclose(fq["g2"][:, 100], 1)
+    from vpc_amd._lib import HIDDEN_POS1 as P1, HIDDEN_POS2 as P2  # unit -> position in the padded width
+    assert np.allclose(fq["h1"][:, P1[100]], 1) and np.allclose(fq["h2"][:, P2[50]], 1)
+    assert np.allclose(fq["g1"][:, P2[50]], 1) and np.allclose(fq["g2"][:, P1[100]], 1)
     assert np.allclose(fq["mu"], cq.mean, atol=1e-6) and np.allclose(fq["lv"], cq.logvar, atol=1e-6)
     assert np.allclose(fq["xh"][:, :d], cq.xhat, atol=1e-6)
-    assert np.allclose(fq["h1"][:, :100], cq.h1, atol=1e-6) and np.allclose(fq["g2"][:, :100], cq.g2, atol=1e-6)
+    assert np.allclose(fq["h1"][:, P1[:100]], cq.h1, atol=1e-6) and np.allclose(fq["g2"][:, P1[:100]], cq.g2, atol=1e-6)
 
     # ---- packed-space backward for the kl_reg loss, scattered into fake partial blocks, gathered by grad_idx
     _, grads, (cq, cp), _ = O.closed_form_reg_step(params, Ld, x, m, mp, eq, ep, alpha=0.7, beta=0.9)

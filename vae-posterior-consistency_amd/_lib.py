@@ -176,3 +176,10 @@ def num_cus() -> int:
     if _NCU is None:
         _NCU = int(lib().vpc_num_cus())
     return _NCU
+
+
+# Positions of the hidden units (index H = the constant-1 unit of the bias chain) inside the padded 112- / 64-wide
+# workspaces and weight images (csrc/vpc_layout.h pos1 / pos2): the last, partly filled tile is laid out j-major so
+# that the MFMA k-steps holding only padding can be skipped.  Only tests and debugging tools need this.
+HIDDEN_POS1 = list(range(96)) + [96, 100, 104, 108, 97]
+HIDDEN_POS2 = list(range(48)) + [48, 52, 56]

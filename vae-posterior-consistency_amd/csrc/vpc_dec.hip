@@ -186,7 +186,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc[NB] = {zero4(), zero4()};
-                    tile_fwd_nb<H2T, 64, NB>(W5, mt, g1, acc, cc, qq);
+                    tile_fwd_nb<H2T, 64, NB, NK2>(W5, mt, g1, acc, cc, qq);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) g2[nb][mt] = relu4(acc[nb]);
                 }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     }
                 };
                 fetch(0, xv_cur, ua_cur, ub_cur);
-                tile_fwd_nb<H1T, 128, NB>(W6, 0, g2, pre_cur, cc, qq);
+                tile_fwd_nb<H1T, 128, NB, NK1>(W6, 0, g2, pre_cur, cc, qq);
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     uint32_t ua_nxt[NB], ub_nxt[NB];
                     if (mt + 1 < DT) {
                         fetch(mt + 1, xv_nxt, ua_nxt, ub_nxt);
-                        tile_fwd_nb<H1T, 128, NB>(W6, mt + 1, g2, pre_nxt, cc, qq);
+                        tile_fwd_nb<H1T, 128, NB, NK1>(W6, mt + 1, g2, pre_nxt, cc, qq);
                     }
                     const int f0 = 16 * mt + 4 * q;
 #pragma unroll
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     for (int mt = 0; mt < H2T; ++mt) {
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 acc[NB] = {VPC_DBG(4) ? dg2[0][mt] : zero4(), VPC_DBG(4) ? dg2[1][mt] : zero4()};
-                        if (!VPC_DBG(4)) tile_T_nb<H1T, 64, NB>(W5, mt, dg2, acc, cc, qq);
+                        if (!VPC_DBG(4)) tile_T_nb_k<H1T, 64, NB, NK1>(W5, mt, dg2, acc, cc, qq);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) dg1[nb][mt] = gate_bits(acc[nb], gm1[nb], mt);
                     }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         }
                     }
                     launder(cc, qq);
-                    tile_T_nb<H2T, S4, NB>(W4, 0, dg1, dzt, cc, qq);
+                    tile_T_nb_k<H2T, S4, NB, NK2>(W4, 0, dg1, dzt, cc, qq);
                 }
             }
             VPC_STAMP(8);

@@ -26,7 +26,7 @@ constexpr int DEC8_WAVES = 8, DEC8_THREADS = 512;
 #define ABL(bit) false
 #endif
 
-template <int KT, int S>
+template <int KT, int S, int NK = 4 * KT>  // NK: k-steps to run (the rest multiply padding zeros)
 __device__ __forceinline__ f32x4 tile_fwd_p2(const float* W, int mt, const f32x4 (&in)[KT], int m, int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
     const float* rowp = W + (16 * mt + m) * S;
@@ -38,12 +38,13 @@ __device__ __forceinline__ f32x4 tile_fwd_p2(const float* W, int mt, const f32x4
         const f32x4 fn = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kn + q) ^ (m & MASK)));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(fa[j], in[kt][j], acc);
+        for (int j = 0; j < 4; ++j)
+            if (4 * kt + j < NK) acc = VPC_MFMA(fa[j], in[kt][j], acc);
         fa = fn;
     }
     return acc;
 }
-template <int KT, int S>
+template <int KT, int S, int NK = 4 * KT>
 __device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (&in)[KT], int m, int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
     const int col = 16 * mt + m;
@@ -53,7 +54,7 @@ __device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            f[j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
+            f[j] = (4 * kt + j < NK) ? W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)] : 0.f;
         }
         return f;
     };
@@ -64,7 +65,8 @@ __device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (
         const f32x4 fn = rd(kt + 1 < KT ? kt + 1 : kt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(fa[j], in[kt][j], acc);
+        for (int j = 0; j < 4; ++j)
+            if (4 * kt + j < NK) acc = VPC_MFMA(fa[j], in[kt][j], acc);
         fa = fn;
     }
     return acc;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    g2[0][mt] = relu4(tile_fwd_p2<H2T, 64>(W5, mt, g1[0], cc, qq));
+                    g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
                 }
                 launder(cc, qq);
                 VPC_STAMP(2);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     uint32_t ua = ua_n, ub = ub_n;
                     if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
                     f32x4 pre[1];
-                    pre[0] = tile_fwd_p2<H1T, 128>(W6, mt, g2[0], cc, qq);
+                    pre[0] = tile_fwd_p2<H1T, 128, NK1>(W6, mt, g2[0], cc, qq);
                     if (VEC) {
                         const uint32_t vm = opaque_mask(ok && (mt < DT / 2 || 16 * mt + 4 * q + 3 < a.d));
                         ua &= vm;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     VPC_CUT();
-                    dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64>(W5, mt, dg2[0], cc, qq), gm1, mt);
+                    dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
                 VPC_STAMP(7);
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
                 launder(cc, qq);
-                tile_T_nb<H2T, S4, 1>(W4, 0, dg1, dzt, cc, qq);
+                tile_T_nb_k<H2T, S4, 1, NK2>(W4, 0, dg1, dzt, cc, qq);
             }
             VPC_STAMP(8);
             // ---------------- KL terms, their seeds, and the total seeds on the encoder outputs (KL part + reparameterisation)

@@ -51,7 +51,7 @@ __device__ __forceinline__ f32x4 gate_bits(f32x4 dy, uint32_t bits, int t) {
 
 // ---- NB batch tiles per wave (decoder kernel, one wave per SIMD): one A fragment feeds NB independent
 // accumulator chains, which hides the 40-cycle dependent-MFMA latency without a second wave on the SIMD.
-template <int KT, int S, int NB>
+template <int KT, int S, int NB, int NK = 4 * KT>  // NK: k-steps to run (the rest multiply padding zeros)
 __device__ __forceinline__ void tile_fwd_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB],
                                             int m, int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
@@ -66,11 +66,12 @@ __device__ __forceinline__ void tile_fwd_nb(const float* W, int mt, const f32x4 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
+            for (int nb = 0; nb < NB; ++nb)
+                if (4 * kt + j < NK) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
 }
-template <int KT, int S, int NB>
-__device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB], int m,
-                                          int q) {
+template <int KT, int S, int NB, int NK>  // NK: k-steps to run (the rest multiply padding zeros)
+__device__ __forceinline__ void tile_T_nb_k(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB], int m,
+                                            int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
     const int col = 16 * mt + m;
     const int cs = col >> 2, cl = col & 3;
@@ -80,18 +81,25 @@ __device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;
-            a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
+            if (4 * kt + j < NK) a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
         }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
+            for (int nb = 0; nb < NB; ++nb)
+                if (4 * kt + j < NK) acc[nb] = VPC_MFMA(a[kt][j], in[nb][kt][j], acc[nb]);
+}
+
+template <int KT, int S, int NB>
+__device__ __forceinline__ void tile_T_nb(const float* W, int mt, const f32x4 (&in)[NB][KT], f32x4 (&acc)[NB], int m,
+                                          int q) {
+    tile_T_nb_k<KT, S, NB, 4 * KT>(W, mt, in, acc, m, q);
 }
 
 // out tile mt of  W[out][in] * in   (A fragments: one ds_read_b128 per 4 MFMAs, all requested up front)
-template <int KT, int S>
+template <int KT, int S, int NK = 4 * KT>  // NK: k-steps to run (the rest multiply padding zeros)
 __device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
                                           int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
@@ -101,16 +109,15 @@ __device__ __forceinline__ f32x4 tile_fwd(const float* W, int mt, const f32x4 (&
     for (int kt = 0; kt < KT; ++kt) a[kt] = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        acc = VPC_MFMA(a[kt][0], in[kt][0], acc);
-        acc = VPC_MFMA(a[kt][1], in[kt][1], acc);
-        acc = VPC_MFMA(a[kt][2], in[kt][2], acc);
-        acc = VPC_MFMA(a[kt][3], in[kt][3], acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * kt + j < NK) acc = VPC_MFMA(a[kt][j], in[kt][j], acc);
     }
     return acc;
 }
 
 // out tile mt of  W^T[in][out] * in  where `in` has KT tiles over W's ROW index (A fragment: 4 x ds_read_b32)
-template <int KT, int S>
+template <int KT, int S, int NK = 4 * KT>
 __device__ __forceinline__ f32x4 tile_T(const float* W, int mt, const f32x4 (&in)[KT], f32x4 acc, int m,
                                         int q) {
     constexpr int MASK = (S / 4 - 1) & 15;
@@ -122,12 +129,13 @@ __device__ __forceinline__ f32x4 tile_T(const float* W, int mt, const f32x4 (&in
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * q + j;  // row & 15
-            a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
+            if (4 * kt + j < NK) a[kt][j] = W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)];
         }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = VPC_MFMA(a[kt][j], in[kt][j], acc);
+        for (int j = 0; j < 4; ++j)
+            if (4 * kt + j < NK) acc = VPC_MFMA(a[kt][j], in[kt][j], acc);
     return acc;
 }
 

@@ -137,12 +137,12 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             f32x4 h2[H2T];
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) {
-                h2[mt] = relu4(tile_fwd<H1T, 128>(W2, mt, h1, zero4(), cc, qq));
+                h2[mt] = relu4(tile_fwd<H1T, 128, NK1>(W2, mt, h1, zero4(), cc, qq));
                 st_tile<true>(a.h2[p], row, H2P, 16 * mt + 4 * q, H2P, ok, h2[mt]);
             }
             VPC_STAMP(3);
-            const f32x4 mu = tile_fwd<H2T, 64>(W3, 0, h2, zero4(), cc, qq);
-            const f32x4 lv = tile_fwd<H2T, 64>(W3, 1, h2, zero4(), cc, qq);
+            const f32x4 mu = tile_fwd<H2T, 64, NK2>(W3, 0, h2, zero4(), cc, qq);
+            const f32x4 lv = tile_fwd<H2T, 64, NK2>(W3, 1, h2, zero4(), cc, qq);
             if (a.lp == 16) {  // padded workspaces: rows are 16 floats, features >= L are exact zeros
                 st_tile<true>(a.mean[p], row, 16, 4 * q, 16, ok, mu);
                 st_tile<true>(a.logvar[p], row, 16, 4 * q, 16, ok, lv);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             f32x4 dh1[H1T];
 #pragma unroll
             for (int mt = 0; mt < H1T; ++mt) {
-                dh1[mt] = gate4(tile_T<H2T, 128>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
+                dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
                 // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then the
                 // c == 0 lanes add into this wave's private LDS row (same lane every time -> fixed order)
                 // (DPP adds, no LDS round trips: the __shfl_xor butterfly is 4 ds_bpermute + 4 waits per value, and the

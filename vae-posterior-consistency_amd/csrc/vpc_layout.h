@@ -32,6 +32,20 @@ namespace vpc {
 constexpr int H1 = 100, H2 = 50;       // hidden widths (hard-coded in the reference)
 constexpr int H1T = 7, H2T = 4;        // tiles
 constexpr int H1P = 112, H2P = 64;     // padded widths (also the row pitch of the h1/h2/g1/g2 workspaces)
+// 4-wide MFMA k-steps that can hold non-zero data when a hidden layer is the K dimension: its real units plus the
+// constant-1 unit of the bias chain; the k-steps behind them multiply exact zeros of the padding and are skipped
+constexpr int NK1 = (H1 + 1 + 3) / 4, NK2 = (H2 + 1 + 3) / 4;  // 26 of 28, 13 of 16
+// Position of hidden unit u (u == H: the constant-1 unit) inside the padded width.  One MFMA k-step (tile t, register j)
+// covers the four positions 16 t + j + 4 q, q = 0..3 - NOT four neighbours - so the units of the last, partly filled
+// tile are laid out j-major: 96, 100, 104, 108, 97 for H1 (k-steps j = 2, 3 of tile 6 hold only padding) and
+// 48, 52, 56 for H2 (j = 1, 2, 3 of tile 3).  Only vpc_build_indices knows this; the kernels see opaque positions.
+VPC_HD constexpr int pos1(int u) { return u < 96 ? u : (u < 100 ? 96 + 4 * (u - 96) : 97); }
+VPC_HD constexpr int pos2(int u) { return u < 48 ? u : 48 + 4 * (u - 48); }
+// bijection of 0..111 that extends pos1: indices past the constant unit go to the padding positions
+VPC_HD inline int pos1_full(int f) {
+    const int pad[H1P - H1 - 1] = {98, 99, 101, 102, 103, 105, 106, 107, 109, 110, 111};
+    return f <= H1 ? pos1(f) : pad[f - H1 - 1];
+}
 constexpr int WAVES = 8;               // waves per workgroup
 constexpr int THREADS = WAVES * 64;
 constexpr int TILE_ROWS = WAVES * 16;  // batch rows per workgroup iteration

@@ -415,58 +415,68 @@ extern "C" int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int
     const ParamOffsets po(d, L, din);
     const int S1 = ei.S1, DB = ei.total;  // decoder image base inside the combined buffer
     std::memset(img_template, 0, sizeof(float) * (size_t)(ei.total + di.total));
-    // ---- encoder layer 1: explicit bias; b1[100] = 1 seeds the constant chain
+    // hidden units sit at pos1(u) / pos2(u) of their padded width (vpc_layout.h): u -> rows of the producing layer,
+    // columns of the consuming layer, positions of the h1 / h2 / g1 / g2 workspaces
+    // ---- encoder layer 1: explicit bias; b1[pos1(100)] = 1 seeds the constant chain
     for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
         for (int i = 0; i < din; ++i) {
-            pack_idx[po.w1 + o * din + i] = ei.oW1 + o * S1 + swz(i, o);
-            grad_idx[po.w1 + o * din + i] = part_off(i >> 4, 4 * (o >> 4), o & 15, i & 15);
+            pack_idx[po.w1 + o * din + i] = ei.oW1 + r * S1 + swz(i, r);
+            grad_idx[po.w1 + o * din + i] = part_off(i >> 4, 4 * (r >> 4), r & 15, i & 15);
         }
-        pack_idx[po.b1 + o] = ei.ob1 + o;
-        grad_idx[po.b1 + o] = WAVES * GREGS * 64 + o;
+        pack_idx[po.b1 + o] = ei.ob1 + r;
+        grad_idx[po.b1 + o] = WAVES * GREGS * 64 + r;
     }
-    img_template[ei.ob1 + H1] = 1.f;
-    // ---- encoder layer 2: bias in column 100; fake row 50 forwards the constant
+    img_template[ei.ob1 + pos1(H1)] = 1.f;
+    // ---- encoder layer 2: bias in the column of h1's constant unit; a fake row forwards the constant to h2
     for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
         for (int i = 0; i <= H1; ++i) {
             const int flat = (i < H1) ? po.w2 + o * H1 + i : po.b2 + o;
-            pack_idx[flat] = ei.oW2 + o * 128 + swz(i, o);
-            grad_idx[flat] = part_off(i >> 4, 28 + 4 * (o >> 4), o & 15, i & 15);
+            const int cI = pos1(i);
+            pack_idx[flat] = ei.oW2 + r * 128 + swz(cI, r);
+            grad_idx[flat] = part_off(cI >> 4, 28 + 4 * (r >> 4), r & 15, cI & 15);
         }
     }
-    img_template[ei.oW2 + H2 * 128 + swz(H1, H2)] = 1.f;
-    // ---- encoder layer 3: mean rows -> tile 0, logvar rows -> tile 1; bias in column 50
+    img_template[ei.oW2 + pos2(H2) * 128 + swz(pos1(H1), pos2(H2))] = 1.f;
+    // ---- encoder layer 3: mean rows -> tile 0, logvar rows -> tile 1; bias in the column of h2's constant unit
     for (int o = 0; o < 2 * L; ++o) {
         const int pr = row3(o, L);
         for (int i = 0; i <= H2; ++i) {
             const int flat = (i < H2) ? po.w3 + o * H2 + i : po.b3 + o;
-            pack_idx[flat] = ei.oW3 + pr * 64 + swz(i, pr);
-            grad_idx[flat] = part_off((pr >> 4) * 4 + (i >> 4), 44, pr & 15, i & 15);
+            const int cI = pos2(i);
+            pack_idx[flat] = ei.oW3 + pr * 64 + swz(cI, pr);
+            grad_idx[flat] = part_off((pr >> 4) * 4 + (cI >> 4), 44, pr & 15, cI & 15);
         }
     }
-    // ---- decoder layer 4: bias in column L (z[L] == 1); fake row 50 forwards the constant
+    // ---- decoder layer 4: bias in column L (z[L] == 1); a fake row forwards the constant to g1
     for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
         for (int i = 0; i <= L; ++i) {
             const int flat = (i < L) ? po.w4 + o * L + i : po.b4 + o;
-            pack_idx[flat] = DB + di.oW4 + o * S4 + swz(i, o, S4);
-            grad_idx[flat] = part_off(o >> 4, 88, o & 15, i & 15, DEC_GREGS);
+            pack_idx[flat] = DB + di.oW4 + r * S4 + swz(i, r, S4);
+            grad_idx[flat] = part_off(r >> 4, 88, r & 15, i & 15, DEC_GREGS);
         }
     }
-    img_template[DB + di.oW4 + H2 * S4 + swz(L, H2, S4)] = 1.f;
-    // ---- decoder layer 5: bias in column 50; fake row 100 forwards the constant
+    img_template[DB + di.oW4 + pos2(H2) * S4 + swz(L, pos2(H2), S4)] = 1.f;
+    // ---- decoder layer 5: bias in the column of g1's constant unit; a fake row forwards the constant to g2
     for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
         for (int i = 0; i <= H2; ++i) {
             const int flat = (i < H2) ? po.w5 + o * H2 + i : po.b5 + o;
-            pack_idx[flat] = DB + di.oW5 + o * 64 + swz(i, o);
-            grad_idx[flat] = part_off((o >> 4) & 3, 56 + 16 * (o >> 6) + 4 * (i >> 4), o & 15, i & 15, DEC_GREGS);
+            const int cI = pos2(i);
+            pack_idx[flat] = DB + di.oW5 + r * 64 + swz(cI, r);
+            grad_idx[flat] = part_off((r >> 4) & 3, 56 + 16 * (r >> 6) + 4 * (cI >> 4), r & 15, cI & 15, DEC_GREGS);
         }
     }
-    img_template[DB + di.oW5 + H1 * 64 + swz(H2, H1)] = 1.f;
-    // ---- decoder layer 6: bias in column 100
+    img_template[DB + di.oW5 + pos1(H1) * 64 + swz(pos2(H2), pos1(H1))] = 1.f;
+    // ---- decoder layer 6: bias in the column of g2's constant unit
     for (int o = 0; o < d; ++o) {
         for (int i = 0; i <= H1; ++i) {
             const int flat = (i < H1) ? po.w6 + o * H1 + i : po.b6 + o;
-            pack_idx[flat] = DB + di.oW6 + o * 128 + swz(i, o);
-            grad_idx[flat] = part_off((o >> 4) & 3, 28 * (o >> 6) + 4 * (i >> 4), o & 15, i & 15, DEC_GREGS);
+            const int cI = pos1(i);
+            pack_idx[flat] = DB + di.oW6 + o * 128 + swz(cI, o);
+            grad_idx[flat] = part_off((o >> 4) & 3, 28 * (o >> 6) + 4 * (cI >> 4), o & 15, cI & 15, DEC_GREGS);
         }
     }
     return VPC_OK;

@@ -25,15 +25,17 @@ constexpr int STAT = 64;  // floats per (n, m): [chain I | chain II] x [mean til
 //   pre[n][m][chain][112]: chain 0 (I) = base + W1[:,T] * mask_T * (xT_carry(m) - x_T),   xT_carry(0) = x_T,
 //                                         xT_carry(m) = im[m-1][n][T]   (temp_x[loc,-1] is not reset, evaluate.py:531-536)
 //                          chain 1 (II) = base + W1[:,T] * (im[m][n][T] - x_T * mask_T)
-//   feature 100 is the constant 1 of the bias chain, 101..111 are 0.
+//   hidden unit f sits at position pos1_full(f) of the 112-wide rows (vpc_layout.h); unit 100 is the constant 1 of the
+//   bias chain, the padding positions are 0.
 __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ im, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, float* __restrict__ pre,
                                                           float* __restrict__ W1T, int n, int d, int M, int Mp) {
-    const int f = threadIdx.x;  // 0..127, features >= 112 idle
+    const int f = threadIdx.x;  // 0..127: hidden unit (100 = constant, 101..111 = padding), >= 112 idle
+    const int pf = f < H1P ? pos1_full(f) : 0;
     if (blockIdx.x == (unsigned)n) {  // last block: W1T[u][f] = W1[f][u]
         for (int u = 0; u < d; ++u)
-            if (f < H1P) W1T[u * H1P + f] = f < H1 ? W1[f * d + u] : 0.f;
+            if (f < H1P) W1T[u * H1P + pf] = f < H1 ? W1[f * d + u] : 0.f;
         return;
     }
     const int r = blockIdx.x, T = d - 1;
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restric
         if (f == H1) p1 = p2 = 1.f;
         if (f > H1) p1 = p2 = 0.f;
         float* o = pre + (((long)r * Mp + m) * 2) * H1P;
-        o[f] = p1;
-        o[H1P + f] = p2;
+        o[pf] = p1;
+        o[H1P + pf] = p2;
     }
 }
 
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) 
 #pragma unroll
             for (int t = 0; t < H2T; ++t) {
                 f32x4 o[2] = {zero4(), zero4()};
-                tile_fwd_nb<H1T, 128, 2>(W2, t, h1, o, cc, qq);
+                tile_fwd_nb<H1T, 128, 2, NK1>(W2, t, h1, o, cc, qq);
                 h2[0][t] = relu4(o[0]);
                 h2[1][t] = relu4(o[1]);
             }
             f32x4 mu[2] = {zero4(), zero4()}, lv[2] = {zero4(), zero4()};
-            tile_fwd_nb<H2T, 64, 2>(W3, 0, h2, mu, cc, qq);
-            tile_fwd_nb<H2T, 64, 2>(W3, 1, h2, lv, cc, qq);
+            tile_fwd_nb<H2T, 64, 2, NK2>(W3, 0, h2, mu, cc, qq);
+            tile_fwd_nb<H2T, 64, 2, NK2>(W3, 1, h2, lv, cc, qq);
             float* st = a.stat + ((long)r * a.Mp + m) * STAT + 4 * q;
             if (MODE == 0) {
                 *reinterpret_cast<f32x4*>(st) = mu[0];
