@@ -302,22 +302,33 @@ __device__ __forceinline__ U4 philox(uint64_t ctr, uint32_t stream, uint64_t see
 __device__ __forceinline__ float u01(uint32_t u) { return ((u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // mask_out = mask_in & (U < keep_prob)   (create_missing_uci * mask, utils.py:36-39 + train.py:54-55)
+// One Philox call serves 8 mask bytes: each 32-bit word gives two 16-bit uniforms (keep probability resolved to
+// 2^-16, far below the sampling noise of any batch).
+constexpr int MASK_PER_CALL = 8;
 __device__ __forceinline__ void draw_mask_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
                                                float keep_prob, uint64_t seed, uint64_t offset, long g) {
-    const long i0 = g * 4;
+    const long i0 = g * MASK_PER_CALL;
     if (i0 >= n) return;
     const U4 r = philox((uint64_t)g + offset, 0u, seed);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-    if (i0 + 3 < n && (((uintptr_t)in | (uintptr_t)out) & 3u) == 0) {
-        const uint32_t u = in ? *reinterpret_cast<const uint32_t*>(in + i0) : 0x01010101u;
-        uint32_t o = 0;
+    const uint32_t thr = (uint32_t)(keep_prob * 65536.f + 0.5f);
+    if (i0 + MASK_PER_CALL - 1 < n && (((uintptr_t)in | (uintptr_t)out) & 7u) == 0) {
+        uint32_t u[2] = {0x01010101u, 0x01010101u}, o[2] = {0u, 0u};
+        if (in) {
+            const uint2 v = *reinterpret_cast<const uint2*>(in + i0);
+            u[0] = v.x; u[1] = v.y;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (((u >> (8 * j)) & 0xffu) && u01(rr[j]) < keep_prob) o |= 1u << (8 * j);
-        *reinterpret_cast<uint32_t*>(out + i0) = o;
+        for (int j = 0; j < MASK_PER_CALL; ++j) {
+            const uint32_t h = (rr[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (((u[j >> 2] >> (8 * (j & 3))) & 0xffu) && h < thr) o[j >> 2] |= 1u << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2*>(out + i0) = make_uint2(o[0], o[1]);
     } else {
-        for (int j = 0; j < 4 && i0 + j < n; ++j)
-            out[i0 + j] = ((in ? in[i0 + j] : 1) && u01(rr[j]) < keep_prob) ? 1 : 0;
+        for (int j = 0; j < MASK_PER_CALL && i0 + j < n; ++j) {
+            const uint32_t h = (rr[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            out[i0 + j] = ((in ? in[i0 + j] : 1) && h < thr) ? 1 : 0;
+        }
     }
 }
 
@@ -331,10 +342,13 @@ __device__ __forceinline__ void fill_normal_body(float* __restrict__ out, long n
     const long i0 = g * 4;
     if (i0 >= n) return;
     const U4 r = philox((uint64_t)g + offset, 1u, seed);
-    const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
-    float s0, c0, s1, c1;
-    sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
-    sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+    // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32 and v_sin / v_cos_f32, whose argument is in
+    // revolutions - exactly the uniform.  (-2 ln u = -2 ln2 log2 u.)
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.z)));
+    const float t0 = u01(r.y), t1 = u01(r.w);
+    const float s0 = __builtin_amdgcn_sinf(t0), c0 = __builtin_amdgcn_cosf(t0);
+    const float s1 = __builtin_amdgcn_sinf(t1), c1 = __builtin_amdgcn_cosf(t1);
     const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
     for (int j = 0; j < 4 && i0 + j < n; ++j) out[i0 + j] = v[j];
 }
@@ -607,7 +621,7 @@ extern "C" int vpc_loss_fwd_bwd(const float* x, int npass, const float* const* x
 extern "C" int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob,
                              unsigned long long seed, unsigned long long offset, void* stream) {
     if (!mask_out || n <= 0) return VPC_ERR_ARG;
-    const long groups = (n + 3) / 4;
+    const long groups = (n + MASK_PER_CALL - 1) / MASK_PER_CALL;
     hipLaunchKernelGGL(draw_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        mask_in, mask_out, n, keep_prob, (uint64_t)seed, (uint64_t)offset);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
@@ -617,7 +631,8 @@ extern "C" int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_m
                              long n_eps, unsigned long long seed, unsigned long long offset_mask,
                              unsigned long long offset_eps, const long long* state, void* stream) {
     if (!mask_out || !eps_out || n_mask <= 0 || n_eps <= 0) return VPC_ERR_ARG;
-    const unsigned gm = (unsigned)(((n_mask + 3) / 4 + 255) / 256), ge = (unsigned)(((n_eps + 3) / 4 + 255) / 256);
+    const unsigned gm = (unsigned)(((n_mask + MASK_PER_CALL - 1) / MASK_PER_CALL + 255) / 256),
+                   ge = (unsigned)(((n_eps + 3) / 4 + 255) / 256);
     hipLaunchKernelGGL(draw_step_kernel, dim3(gm + ge), dim3(256), 0, (hipStream_t)stream, mask_in, mask_out, n_mask,
                        keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm, state);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
