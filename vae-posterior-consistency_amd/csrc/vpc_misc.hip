@@ -173,6 +173,105 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restric
     }
 }
 
+// ---- the same reduction walking the partial blocks in LAYOUT order: each thread sums one 16-byte group of block
+// positions (fully coalesced 16 B / lane instead of 4 B / lane gathers through grad_idx), then scatters the four sums
+// through the inverse map position -> parameter (-1 = padding).  Same per-element summation order as reduce_body
+// (two interleaved accumulators per block group, fixed 8-group combine): bit-identical results.
+__device__ __forceinline__ void reduce_body_v2(const float* __restrict__ part, int nblocks, long stride,
+                                               const int* __restrict__ inv, float* __restrict__ out, int n4, int blk,
+                                               f32x4 (*sh)[32], const AdamFuse* adam) {
+    const int pi = threadIdx.x & 31, bg = threadIdx.x >> 5;
+    const int p4 = blk * 32 + pi;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (p4 < n4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part) + p4;
+        const long st4 = stride >> 2;
+        int b = bg;
+        for (; b + 8 < nblocks; b += 16) {
+            s0 += p[(long)b * st4];
+            s1 += p[(long)(b + 8) * st4];
+        }
+        if (b < nblocks) s0 += p[(long)b * st4];
+    }
+    sh[bg][pi] = s0 + s1;
+    __syncthreads();
+    if (bg == 0 && p4 < n4) {
+        f32x4 t = sh[0][pi];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][pi];
+        const int4 id = reinterpret_cast<const int4*>(inv)[p4];
+        const int ids[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ids[k] >= 0) {
+                out[ids[k]] = t[k];
+                if (adam && adam->param) adam_apply(*adam, ids[k], t[k]);
+            }
+    }
+}
+__global__ __launch_bounds__(256) void reduce_step_v2_kernel(const float* __restrict__ partE, int nbE, long strideE,
+                                                             const float* __restrict__ partD, int nbD, long strideD,
+                                                             const int* __restrict__ invE, const int* __restrict__ invD,
+                                                             float* __restrict__ grad, const double* __restrict__ lp,
+                                                             int nbL, LossCoef k, float* __restrict__ out9,
+                                                             float* __restrict__ accum, long long* __restrict__ state,
+                                                             long long rng_inc, AdamFuse adam) {
+    __shared__ f32x4 shf[8][32];
+    __shared__ double shd[32][LOSS_TERMS];
+    __shared__ double s[LOSS_TERMS];
+    const int nE4 = (int)(strideE >> 2), nD4 = (int)(strideD >> 2);
+    const int gE = (nE4 + 31) / 32, gD = (nD4 + 31) / 32;
+    const int b = blockIdx.x;
+    if (b < gE) reduce_body_v2(partE, nbE, strideE, invE, grad, nE4, b, shf, &adam);
+    else if (b < gE + gD) reduce_body_v2(partD, nbD, strideD, invD, grad, nD4, b - gE, shf, &adam);
+    else {
+        finalize_body(lp, nbL, k, out9, accum, shd, s);
+        if (state && threadIdx.x == 0) {
+            state[0] += 1;
+            state[1] += rng_inc;
+        }
+    }
+}
+// inverse maps (block position -> flat parameter index, -1 for padding), built on first use for a given grad_idx and
+// kept for the life of the process (one layout per model; a new grad_idx pointer or shape rebuilds them)
+__global__ void inv_fill_kernel(int* __restrict__ inv, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[i] = -1;
+}
+__global__ void inv_scatter_kernel(const int* __restrict__ idx, int* __restrict__ invE, int* __restrict__ invD, int n_enc,
+                                   int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i < n_enc) invE[idx[i]] = i; else invD[idx[i]] = i;
+}
+struct InvCache {
+    const int* key = nullptr;
+    int n_enc = 0, n = 0;
+    long sE = 0, sD = 0;
+    int* inv = nullptr;  // [sE | sD]
+};
+static InvCache g_inv;
+// returns the device maps, or false when they cannot be used (unaligned operands) or built right now (stream capture)
+static bool inverse_maps(const int* grad_idx, int n_enc, int n, const float* pe, long sE, const float* pd, long sD,
+                         hipStream_t s, const int** invE, const int** invD) {
+    if ((sE & 3) || (sD & 3) || !aligned16(pe) || !aligned16(pd)) return false;
+    if (g_inv.key != grad_idx || g_inv.n_enc != n_enc || g_inv.n != n || g_inv.sE != sE || g_inv.sD != sD) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+        if (g_inv.inv) (void)hipFree(g_inv.inv);
+        g_inv = InvCache{};
+        int* buf = nullptr;
+        if (hipMalloc(&buf, sizeof(int) * (size_t)(sE + sD)) != hipSuccess) return false;
+        hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)((sE + sD + 255) / 256)), dim3(256), 0, s, buf, sE + sD);
+        hipLaunchKernelGGL(inv_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, grad_idx, buf, buf + sE, n_enc, n);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(buf); return false; }
+        g_inv.key = grad_idx; g_inv.n_enc = n_enc; g_inv.n = n; g_inv.sE = sE; g_inv.sD = sD; g_inv.inv = buf;
+    }
+    *invE = g_inv.inv;
+    *invD = g_inv.inv + sE;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: stand-alone fused loss (API path: model.loss(...) on materialised tensors).
 // One pass over x / xhat_q / xhat_p / masks / latent stats; per-block double partials; optional seeds.
@@ -551,6 +650,15 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
         return VPC_ERR_ARG;
     const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
                      1.0 / (double)B_global};
+    const int *invE = nullptr, *invD = nullptr;
+    if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
+                     &invD)) {
+        const int grid2 = (int)((enc_stride / 4 + 31) / 32 + (dec_stride / 4 + 31) / 32 + 1);
+        hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                           enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
+                           loss_blocks, k, out9, accum, state, rng_inc, AdamFuse{});
+        return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+    }
     const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
     hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                        enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
@@ -573,6 +681,15 @@ extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, l
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2)};
+    const int *invE = nullptr, *invD = nullptr;
+    if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
+                     &invD)) {
+        const int grid2 = (int)((enc_stride / 4 + 31) / 32 + (dec_stride / 4 + 31) / 32 + 1);
+        hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                           enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
+                           loss_blocks, k, out9, accum, (long long*)nullptr, 0LL, A);
+        return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+    }
     const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
     hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                        enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
