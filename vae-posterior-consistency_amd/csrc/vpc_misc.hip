@@ -176,37 +176,36 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(const float* __restric
 // ---- the same reduction walking the partial blocks in LAYOUT order: each thread sums one 16-byte group of block
 // positions (fully coalesced 16 B / lane instead of 4 B / lane gathers through grad_idx), then scatters the four sums
 // through the inverse map position -> parameter (-1 = padding).  Same per-element summation order as reduce_body
-// (two interleaved accumulators per block group, fixed 8-group combine): bit-identical results.
+// -1 = padding).  Summation order: blocks g, g + 32, ... per group, then groups 0..31 (fixed: reproducible).
 __device__ __forceinline__ void reduce_body_v2(const float* __restrict__ part, int nblocks, long stride,
                                                const int* __restrict__ inv, float* __restrict__ out, int n4, int blk,
-                                               f32x4 (*sh)[32], const AdamFuse* adam) {
-    const int pi = threadIdx.x & 31, bg = threadIdx.x >> 5;
-    const int p4 = blk * 32 + pi;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                                               f32x4 (*sh)[8], const AdamFuse* adam) {
+    // 8 positions x 32 block groups per workgroup: with 256 blocks every thread has its 8 loads in flight at once (one
+    // memory latency for the whole reduction), a wave touches full 128-byte lines, and the launch has ~6 workgroups/CU
+    const int pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
+    const int p4 = blk * 8 + pi;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
     if (p4 < n4) {
         const f32x4* p = reinterpret_cast<const f32x4*>(part) + p4;
         const long st4 = stride >> 2;
-        int b = bg;
-        for (; b + 8 < nblocks; b += 16) {
-            s0 += p[(long)b * st4];
-            s1 += p[(long)(b + 8) * st4];
-        }
-        if (b < nblocks) s0 += p[(long)b * st4];
+#pragma unroll 8
+        for (int b = bg; b < nblocks; b += 32) s0 += p[(long)b * st4];
     }
-    sh[bg][pi] = s0 + s1;
+    sh[bg][pi] = s0;
     __syncthreads();
-    if (bg == 0 && p4 < n4) {
-        f32x4 t = sh[0][pi];
+    if (threadIdx.x < 32) {  // one thread per element: fixed-order combine of the 32 groups, then the optimiser step
+        const int pos = threadIdx.x >> 2, k = threadIdx.x & 3;
+        const int e = 4 * (blk * 8 + pos) + k;
+        if (blk * 8 + pos < n4) {
+            float t = sh[0][pos][k];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += sh[k][pi];
-        const int4 id = reinterpret_cast<const int4*>(inv)[p4];
-        const int ids[4] = {id.x, id.y, id.z, id.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ids[k] >= 0) {
-                out[ids[k]] = t[k];
-                if (adam && adam->param) adam_apply(*adam, ids[k], t[k]);
+            for (int g = 1; g < 32; ++g) t += sh[g][pos][k];
+            const int id = inv[e];
+            if (id >= 0) {
+                out[id] = t;
+                if (adam && adam->param) adam_apply(*adam, id, t);
             }
+        }
     }
 }
 __global__ __launch_bounds__(256) void reduce_step_v2_kernel(const float* __restrict__ partE, int nbE, long strideE,
@@ -216,11 +215,11 @@ __global__ __launch_bounds__(256) void reduce_step_v2_kernel(const float* __rest
                                                              int nbL, LossCoef k, float* __restrict__ out9,
                                                              float* __restrict__ accum, long long* __restrict__ state,
                                                              long long rng_inc, AdamFuse adam) {
-    __shared__ f32x4 shf[8][32];
+    __shared__ f32x4 shf[32][8];
     __shared__ double shd[32][LOSS_TERMS];
     __shared__ double s[LOSS_TERMS];
     const int nE4 = (int)(strideE >> 2), nD4 = (int)(strideD >> 2);
-    const int gE = (nE4 + 31) / 32, gD = (nD4 + 31) / 32;
+    const int gE = (nE4 + 7) / 8, gD = (nD4 + 7) / 8;
     const int b = blockIdx.x;
     if (b < gE) reduce_body_v2(partE, nbE, strideE, invE, grad, nE4, b, shf, &adam);
     else if (b < gE + gD) reduce_body_v2(partD, nbD, strideD, invD, grad, nD4, b - gE, shf, &adam);
@@ -653,7 +652,7 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
     const int *invE = nullptr, *invD = nullptr;
     if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
                      &invD)) {
-        const int grid2 = (int)((enc_stride / 4 + 31) / 32 + (dec_stride / 4 + 31) / 32 + 1);
+        const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);
         hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                            enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
                            loss_blocks, k, out9, accum, state, rng_inc, AdamFuse{});
@@ -684,7 +683,7 @@ extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, l
     const int *invE = nullptr, *invD = nullptr;
     if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
                      &invD)) {
-        const int grid2 = (int)((enc_stride / 4 + 31) / 32 + (dec_stride / 4 + 31) / 32 + 1);
+        const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);
         hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                            enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
                            loss_blocks, k, out9, accum, (long long*)nullptr, 0LL, A);
