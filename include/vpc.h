@@ -134,7 +134,12 @@ int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float
  * post-backward reduction of the fused step.  grad_out[0, n_enc) from the encoder blocks, [n_enc, n) from the
  * decoder blocks (grad_idx as returned by vpc_build_indices), out9 / accum as vpc_loss_finalize.  If state != NULL
  * (two int64 words on the device) the kernel also does state[0] += 1 (optimiser step count) and
- * state[1] += rng_inc (Philox counter offset): the per-step counters of a replayed HIP graph. */
+ * state[1] += rng_inc (Philox counter offset): the per-step counters of a replayed HIP graph.
+ * When both strides are multiples of 4 floats and the block pointers 16-byte aligned (true for the blocks the
+ * kernels above write) the blocks are read in layout order, 16 bytes per lane, through an inverse map
+ * (block position -> parameter) that the library builds on the first call for a given grad_idx pointer and keeps
+ * (one small device allocation per process; not rebuilt inside a stream capture - call once eagerly first).
+ * Summation order is fixed either way (reproducible), but differs between the two forms in the last bits. */
 int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
                     int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
                     const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq, float bp,
@@ -154,7 +159,8 @@ int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_str
 /* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
 
 /* mask_out = mask_in AND (U < keep_prob): create_missing_uci(shape, rate) * mask with keep_prob = 1 - rate/100
- * (src/utils/utils.py:36-39, src/experiment_main/train.py:53-55).  mask_in NULL = all ones. */
+ * (src/utils/utils.py:36-39, src/experiment_main/train.py:53-55).  mask_in NULL = all ones.  U has 16 random
+ * bits (one Philox call serves 8 elements; element i uses counter i / 8 + offset): keep_prob is resolved to 2^-16. */
 int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob, unsigned long long seed,
                   unsigned long long offset, void* stream);
 
