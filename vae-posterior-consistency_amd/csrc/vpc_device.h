@@ -228,6 +228,21 @@ __device__ __forceinline__ f32x4 ld_tile_o(const float* base, long row, int ld, 
     }
     return v;
 }
+// ---- raw buffer access for row-tiled workspaces: the descriptor covers the rows [row0, B) of a [B][pitch] fp32 array, so a
+// lane whose row is past B is out of range and its store is dropped (its load returns 0) by the hardware's range check -
+// no `if (row_ok)` around the access, hence no exec-masked basic block per store and no vmcnt(0) join per load.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float* base, long row0, long B, int pitch) {
+    const long rem = (B - row0) * (long)pitch * 4;  // bytes from row0 to the end of the array
+    const uint32_t rec = rem <= 0 ? 0u : (rem > 0xffffffffL ? 0xffffffffu : (uint32_t)rem);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + row0 * pitch, 0, rec, 0x00020000);
+}
+__device__ __forceinline__ void st_rows(__amdgpu_buffer_rsrc_t r, int local_row, int pitch, int f0, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (local_row * pitch + f0) * 4, 0, 0);
+}
+__device__ __forceinline__ f32x4 ld_rows(__amdgpu_buffer_rsrc_t r, int local_row, int pitch, int f0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (local_row * pitch + f0) * 4, 0, 0));
+}
 template <bool VEC>
 __device__ __forceinline__ void st_tile(float* base, long row, int ld, int f0, int nvalid, bool row_ok, f32x4 v) {
     float* p = base + row * ld + f0;

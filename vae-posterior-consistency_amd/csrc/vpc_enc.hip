@@ -105,6 +105,10 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             asm volatile("" ::: "memory");
             int cc = c, qq = q;
             launder(cc, qq);
+            // workspace stores go through range-checked buffer descriptors (rows past B are dropped by the hardware)
+            const long row0 = (long)tile * TILE_ROWS;
+            const int lrow = w * 16 + c;
+            const __amdgpu_buffer_rsrc_t rh1 = rows_rsrc(a.h1[p], row0, a.B, H1P), rh2 = rows_rsrc(a.h2[p], row0, a.B, H2P);
             f32x4 xin[DT];
             if (PIPE) {
 #pragma unroll
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                 f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
                 acc = tile_fwd<DT, S1>(W1, mt, xin, acc, cc, qq);
                 h1[mt] = relu4(acc);
-                st_tile<true>(a.h1[p], row, H1P, 16 * mt + 4 * q, H1P, ok, h1[mt]);
+                st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
             }
             VPC_STAMP(2);
             launder(cc, qq);
@@ -138,14 +142,14 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) {
                 h2[mt] = relu4(tile_fwd<H1T, 128, NK1>(W2, mt, h1, zero4(), cc, qq));
-                st_tile<true>(a.h2[p], row, H2P, 16 * mt + 4 * q, H2P, ok, h2[mt]);
+                st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
             }
             VPC_STAMP(3);
             const f32x4 mu = tile_fwd<H2T, 64, NK2>(W3, 0, h2, zero4(), cc, qq);
             const f32x4 lv = tile_fwd<H2T, 64, NK2>(W3, 1, h2, zero4(), cc, qq);
             if (a.lp == 16) {  // padded workspaces: rows are 16 floats, features >= L are exact zeros
-                st_tile<true>(a.mean[p], row, 16, 4 * q, 16, ok, mu);
-                st_tile<true>(a.logvar[p], row, 16, 4 * q, 16, ok, lv);
+                st_rows(rows_rsrc(a.mean[p], row0, a.B, 16), lrow, 16, 4 * q, mu);
+                st_rows(rows_rsrc(a.logvar[p], row0, a.B, 16), lrow, 16, 4 * q, lv);
             } else {
                 st_tile<false>(a.mean[p], row, a.L, 4 * q, a.L, ok, mu);
                 st_tile<false>(a.logvar[p], row, a.L, 4 * q, a.L, ok, lv);
