@@ -220,9 +220,9 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     int sb[4];  // per-lane element offsets of the staging writes (tile 0); tiles add a compile-time constant
     stage_bases<CH>(sb, 16 * w, c, q);
 
-    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4();
+    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4(), dbacc[H1T];
 #pragma unroll
-    for (int i = 0; i < H1T; ++i) acc1[i] = zero4();
+    for (int i = 0; i < H1T; ++i) acc1[i] = dbacc[i] = zero4();
 #pragma unroll
     for (int i = 0; i < H2T; ++i) acc2[i] = zero4();
 
@@ -355,20 +355,10 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < H1T; ++mt) {
                 dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
-                // db1 += sum over this wave's 16 rows (lanes c): butterfly inside each 16-lane group, then the
-                // c == 0 lanes add into this wave's private LDS row (same lane every time -> fixed order)
-                // (DPP adds, no LDS round trips: the __shfl_xor butterfly is 4 ds_bpermute + 4 waits per value, and the
-                // read-modify-write behind it two more - for 28 values per pass that chain cost as many cycles as all
-                // MFMAs of the pass.  ds_add_f32 without return needs no wait; one lane per address -> fixed order.)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = dh1[mt][j];
-                    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-                    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-                    v += dpp_mov<0x141>(v);  // row_half_mirror
-                    v += dpp_mov<0x140>(v);  // row_mirror: every lane of the 16-lane row holds the row sum
-                    if (c == 0) atomicAdd(&db1s[w * 128 + 16 * mt + 4 * q + j], v);
-                }
+                // db1: per-lane running sums over all tile-passes; the cross-lane reduction happens ONCE, after the
+                // loops (it used to be 4 DPP adds + a predicated ds_add per value and pass: ~170 VALU and 28 exec-masked
+                // basic blocks in the middle of the dgrad MFMA stream)
+                dbacc[mt] += dh1[mt];
             }
             VPC_STAMP(4);
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles; B straight from global)
@@ -399,6 +389,19 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             VPC_STAMP(5);
         }
     }
+    // ---- db1 = sum of dh1 over this wave's 16 rows (lanes c): DPP butterfly inside each 16-lane row, then the c == 0
+    // lanes own one (wave, feature) slot each - plain stores, fixed order, bit-reproducible
+#pragma unroll
+    for (int mt = 0; mt < H1T; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = dbacc[mt][j];
+            v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+            v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+            v += dpp_mov<0x141>(v);  // row_half_mirror
+            v += dpp_mov<0x140>(v);  // row_mirror: every lane of the 16-lane row holds the row sum
+            if (c == 0) db1s[w * 128 + 16 * mt + 4 * q + j] = v;
+        }
     // ---- write this workgroup's gradient partial block
     float* part = a.part + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
 #pragma unroll
