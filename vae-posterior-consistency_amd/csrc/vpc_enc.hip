@@ -242,21 +242,22 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             VPC_STAMP(0);
             // B fragments of slice s (batch rows row0 + 16 s + 4 q + j): raw x and mask bytes; rows past B read row 0
             // (their dh1 is exactly zero), columns past the input width are cleared when the fragment is formed
-            // 32-bit offsets from a per-tile (uniform) base, formed from the laundered lane id when a slice is
-            // requested: hipcc otherwise precomputes all 32 64-bit row addresses per tile and spills them
-            const float* xt = a.x + row0 * a.d;
-            const uint8_t* mt = a.mask[p] + row0 * a.d;
-            const long lastrow = a.B - 1 - row0;
-            const unsigned lim = (unsigned)(lastrow < TILE_ROWS - 1 ? lastrow : TILE_ROWS - 1);
+            // range-checked buffer loads relative to the tile's first row: a row past B is out of range and reads 0 (x and
+            // mask byte), so no clamp; per load one 32-bit add of the slice offset to a per-lane base (the range check
+            // covers voffset only, so the slice offset must not go into soffset).  Formed from the laundered lane id:
+            // hipcc otherwise precomputes all 32 addresses per tile and spills them.
+            const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
+            const long mrem = (a.B - row0) * (long)a.d;
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(a.mask[p]) + row0 * a.d, 0, mrem > 0xffffffffL ? 0xffffffffu : (uint32_t)mrem, 0x00020000);
+            const int vo0 = 4 * qq * a.d + colB;  // element offset of (row 4 q, this lane's column)
             auto ld_xb = [&](int sl, f32x4& xv, uint32_t& mb) {
                 mb = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    unsigned lr = 16u * sl + 4u * (unsigned)qq + j;
-                    lr = lr < lim ? lr : lim;
-                    const unsigned o = lr * (unsigned)a.d + (unsigned)colB;
-                    xv[j] = xt[o];
-                    mb |= (uint32_t)mt[o] << (8 * j);
+                    const int o = vo0 + (16 * sl + j) * a.d;
+                    xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4 * o, 0, 0));
+                    mb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rm, o, 0, 0) << (8 * j);
                 }
             };
             auto mk_fb = [&](const f32x4& xv, uint32_t mb) -> f32x4 {
