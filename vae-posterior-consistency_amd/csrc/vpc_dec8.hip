@@ -99,11 +99,17 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     constexpr float HL2PI = 0.91893853320467274f;
     const bool own6 = w < DT, own5 = w < H1T, own4 = w < H2T;
 
-    auto ld_lat = [&](const float* base, long r, bool rok) -> f32x4 { return ld_tile_o<true>(base, r, 16, 4 * q, 16, rok); };
-    auto st_lat = [&](float* base, long r, bool rok, f32x4 v) {
+    // latent-width ([B][16]) arrays go through range-checked buffer descriptors over the rows [row0, B): a row past B
+    // reads 0 / is not written, and an absent optional array (NULL) gets an empty descriptor and reads 0 - no address
+    // clamps, no masking VALU, no exec-masked store blocks
+    const int lrow = (threadIdx.x >> 6) * 16 + (threadIdx.x & 15);
+    auto ld_lat = [&](const float* base, long row0) -> f32x4 {
+        return ld_rows(rows_rsrc(base ? base : a.mean[0], row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
+    };
+    auto st_lat = [&](float* base, long row0, f32x4 v) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (4 * q + j < a.L) ? v[j] : 0.f;
-        st_tile<true>(base, r, 16, 4 * q, 16, rok, v);
+        st_rows(rows_rsrc(base, row0, a.B, 16), lrow, 16, 4 * q, v);
     };
 
     f32x4 acc6[H1T], acc5[H2T], acc4 = zero4();
@@ -114,7 +120,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long row = (long)tile * TILE_ROWS + w * 16 + c;
+        const long row0 = (long)tile * TILE_ROWS;
+        const long row = row0 + w * 16 + c;
         const bool ok = row < a.B;
         for (int p = 0; p < a.npass; ++p) {
             asm volatile("" ::: "memory");  // keep LDS weight reads inside the pass (see vpc_enc.hip)
@@ -126,22 +133,21 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
             const bool two = a.npass == 2;
             f32x4 z[1][1];
             {
-                const f32x4 mu = ld_lat(a.mean[p], row, ok);
-                const f32x4 lv = ld_lat(a.logvar[p], row, ok);
-                const f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
+                const f32x4 mu = ld_lat(a.mean[p], row0);
+                const f32x4 lv = ld_lat(a.logvar[p], row0);
+                const f32x4 e = ld_lat(a.eps[p], row0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)  // padded eps rows hold noise
                     z[0][0][j] = mu[j] + ((4 * q + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
             }
             f32x4 mu, lv, e, mo, lo, e3;  // pass-end operands
             auto fetch_stats = [&]() {
-                mu = ld_lat(a.mean[p], row, ok);
-                lv = ld_lat(a.logvar[p], row, ok);
-                e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row, ok), opaque_mask(a.eps[p] != nullptr));
-                const uint32_t has_o = opaque_mask(two);
-                mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row, ok), has_o);
-                lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row, ok), has_o);
-                e3 = and4(ld_lat(a.eps_ml ? a.eps_ml : a.mean[p], row, ok), opaque_mask(a.eps_ml != nullptr));
+                mu = ld_lat(a.mean[p], row0);
+                lv = ld_lat(a.logvar[p], row0);
+                e = ld_lat(a.eps[p], row0);
+                mo = ld_lat(two ? a.mean[1 - p] : nullptr, row0);
+                lo = ld_lat(two ? a.logvar[1 - p] : nullptr, row0);
+                e3 = ld_lat(a.eps_ml, row0);
             };
             VPC_STAMP(1);
             VPC_CUT();
@@ -175,27 +181,26 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 float sa = 0.f, se = 0.f;
                 const bool hasB = a.mB[p] != nullptr;
                 const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
-                const float* xl;
-                const uint32_t* mal;
-                const uint32_t* mbl;
-                {
-                    const int cq = (VEC && 4 * q + 3 < a.d) ? 4 * q : 0;
-                    const long ro = (ok ? row : 0) * a.d + cq;
-                    xl = a.x + ro;
-                    mal = reinterpret_cast<const uint32_t*>(a.mA[p] + ro);
-                    mbl = reinterpret_cast<const uint32_t*>((hasB ? a.mB[p] : a.mA[p]) + ro);
-                }
                 // x / mask words of tile mt + 1 are requested before tile mt's MFMAs and consumed after the next tile's: a
-                // wave never sits on a vmcnt wait in front of its MFMAs.  Out-of-range rows / columns read row 0 /
-                // column 0 (valid memory); their mask words are cleared below, so they carry zero weight.
+                // wave never sits on a vmcnt wait in front of its MFMAs.  Range-checked buffer loads relative to the
+                // tile's first row: a row past B reads 0 (zero mask = zero weight); out-of-range columns (possible in the
+                // last DT / 2 tiles only, by dt_for) read column 0 and have their mask words cleared below.
+                const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
+                const long mrem = (a.B - row0) * (long)a.d;
+                const uint32_t mrec = mrem > 0xffffffffL ? 0xffffffffu : (uint32_t)mrem;
+                const __amdgpu_buffer_rsrc_t rmA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.mA[p]) + row0 * a.d,
+                                                                                     0, mrec, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rmB = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint8_t*>(hasB ? a.mB[p] : a.mA[p]) + row0 * a.d, 0, mrec, 0x00020000);
+                const int vo = lrow * a.d + ((VEC && 4 * q + 3 < a.d) ? 4 * q : 0);  // element offset inside the tile's rows
                 auto fetch = [&](int mt, f32x4& xv, uint32_t& ua, uint32_t& ub) {
                     const int f0 = 16 * mt + 4 * q;
                     if (VEC) {
                         // d > 16 * DT / 2 (dt_for): the first DT / 2 tiles have no out-of-range columns and are immediate offsets
                         const int fo = (mt < DT / 2 || f0 + 3 < a.d) ? 16 * mt : 0;
-                        xv = *reinterpret_cast<const f32x4*>(xl + fo);
-                        ua = mal[fo >> 2];
-                        ub = mbl[fo >> 2];
+                        xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + fo), 0, 0));
+                        ua = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + fo, 0, 0);
+                        ub = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmB, vo + fo, 0, 0);
                     } else {
                         xv = ld_tile<false>(a.x, row, a.d, f0, a.d, ok);
                         ua = ld_mask_raw<false>(a.mA[p], row, a.d, f0, a.d, ok);
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
                     f32x4 pre[1];
                     pre[0] = tile_fwd_p2<H1T, 128, NK1>(W6, mt, g2[0], cc, qq);
-                    if (VEC) {
-                        const uint32_t vm = opaque_mask(ok && (mt < DT / 2 || 16 * mt + 4 * q + 3 < a.d));
+                    if (VEC && mt >= DT / 2) {
+                        const uint32_t vm = opaque_mask(16 * mt + 4 * q + 3 < a.d);
                         ua &= vm;
                         ub &= vm;
                     }
@@ -405,14 +410,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
                 if (skip_dec) {
-                    st_lat(a.dmean[p], row, ok, dmu_kl);
-                    st_lat(a.dlogvar[p], row, ok, dlv_kl);
+                    st_lat(a.dmean[p], row0, dmu_kl);
+                    st_lat(a.dlogvar[p], row0, dlv_kl);
                 } else {
                     f32x4 ef;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ef[j] = (4 * q + j < a.L) ? e[j] * 0.5f * __expf(0.5f * lv[j]) : 0.f;
-                    st_lat(a.dmean[p], row, ok, dmu_kl + dzt[0]);
-                    st_lat(a.dlogvar[p], row, ok, dlv_kl + dzt[0] * ef);
+                    st_lat(a.dmean[p], row0, dmu_kl + dzt[0]);
+                    st_lat(a.dlogvar[p], row0, dlv_kl + dzt[0] * ef);
                 }
             }
         }
