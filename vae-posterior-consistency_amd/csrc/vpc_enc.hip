@@ -79,21 +79,27 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
     f32x4 xraw[DT];
     uint32_t mw[DT];
     const int cq = (4 * q + 3 < a.d) ? 4 * q : 0;
-    auto fetch_x = [&](long r) {
-        const float* xl = a.x + (r < a.B ? r : 0) * a.d + cq;
+    // range-checked buffer loads relative to a tile's first row t0 (rows past B read 0)
+    const int vo = (w * 16 + c) * a.d + cq;  // element offset of this lane's row / column group inside the tile's rows
+    auto fetch_x = [&](long t0) {
+        const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, t0, a.B, a.d);
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-            xraw[t] = *reinterpret_cast<const f32x4*>(xl + ((t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0));
+            xraw[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rx, 4 * (vo + ((t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0)), 0, 0));
     };
-    auto fetch_m = [&](const uint8_t* m, long r) {
-        const uint32_t* ml = reinterpret_cast<const uint32_t*>(m + (r < a.B ? r : 0) * a.d + cq);
+    auto fetch_m = [&](const uint8_t* m, long t0) {
+        const long rem = (a.B - t0) * (long)a.d;
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(m) + t0 * a.d, 0, rem > 0xffffffffL ? 0xffffffffu : (uint32_t)rem, 0x00020000);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) mw[t] = ml[(t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 4 * t : 0];
+        for (int t = 0; t < DT; ++t)
+            mw[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                rm, vo + ((t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0), 0, 0);
     };
     if (PIPE && (int)blockIdx.x < a.ntiles) {
-        const long r0 = (long)blockIdx.x * TILE_ROWS + w * 16 + c;
-        fetch_x(r0);
-        fetch_m(a.mask[0], r0);
+        fetch_x((long)blockIdx.x * TILE_ROWS);
+        fetch_m(a.mask[0], (long)blockIdx.x * TILE_ROWS);
     }
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -117,11 +123,11 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                     xin[t] = xraw[t] * mask_to_f32(mw[t] & vm);  // x.float() * mask  (VAE.py:388)
                 }
                 if (p + 1 < a.npass) {
-                    fetch_m(a.mask[p + 1], row);
+                    fetch_m(a.mask[p + 1], row0);
                 } else if (tile + (int)gridDim.x < a.ntiles) {
-                    const long rn = row + (long)gridDim.x * TILE_ROWS;
-                    fetch_x(rn);
-                    fetch_m(a.mask[0], rn);
+                    const long tn = row0 + (long)gridDim.x * TILE_ROWS;
+                    fetch_x(tn);
+                    fetch_m(a.mask[0], tn);
                 }
             } else {
 #pragma unroll
