@@ -273,28 +273,24 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 for (int j = 0; j < 4; ++j) v[j] = fx ? xv[j] * m[j] : (fm ? m[j] : 0.f);
                 return v;
             };
-            // PIPE (the vectorised fast path): branch-free loads - rows past B read row 0 and only the seeds dml are
-            // masked: zero seeds make dh2, dh1 and every wgrad contribution of such a row exactly zero, whatever h1 /
-            // h2 / x hold.  (hipcc turns `ok ? load : 0` into an exec-masked branch with a vmcnt(0) wait at the join.)
-            const long rowc = ok ? row : 0;
+            // row-layout operands through range-checked buffer descriptors: rows past B read 0 - zero seeds make dh2, dh1
+            // and every wgrad contribution of such a row exactly zero.  (hipcc turns `ok ? load : 0` into an exec-masked
+            // branch with a vmcnt(0) wait at the join.)
+            const int lrow = w * 16 + c;
             f32x4 dml[2], h2[H2T], h1[H1T];
             if (a.lp == 16) {
-                dml[0] = PIPE ? ld_tile_o<true>(a.dmean[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dmean[p], row, 16, 4 * q, 16, ok);
-                dml[1] = PIPE ? ld_tile_o<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok) : ld_tile<true>(a.dlogvar[p], row, 16, 4 * q, 16, ok);
+                dml[0] = ld_rows(rows_rsrc(a.dmean[p], row0, a.B, 16), lrow, 16, 4 * q);
+                dml[1] = ld_rows(rows_rsrc(a.dlogvar[p], row0, a.B, 16), lrow, 16, 4 * q);
             } else {
                 dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
                 dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
             }
-            if (PIPE) {
+            {
+                const __amdgpu_buffer_rsrc_t rh2 = rows_rsrc(a.h2[p], row0, a.B, H2P), rh1 = rows_rsrc(a.h1[p], row0, a.B, H1P);
 #pragma unroll
-                for (int t = 0; t < H2T; ++t) h2[t] = *reinterpret_cast<const f32x4*>(a.h2[p] + rowc * H2P + 16 * t + 4 * q);
+                for (int t = 0; t < H2T; ++t) h2[t] = ld_rows(rh2, lrow, H2P, 16 * t + 4 * q);
 #pragma unroll
-                for (int t = 0; t < H1T; ++t) h1[t] = *reinterpret_cast<const f32x4*>(a.h1[p] + rowc * H1P + 16 * t + 4 * q);
-            } else {
-#pragma unroll
-                for (int t = 0; t < H2T; ++t) h2[t] = ld_tile<true>(a.h2[p], row, H2P, 16 * t + 4 * q, H2P, ok);
-#pragma unroll
-                for (int t = 0; t < H1T; ++t) h1[t] = ld_tile<true>(a.h1[p], row, H1P, 16 * t + 4 * q, H1P, ok);
+                for (int t = 0; t < H1T; ++t) h1[t] = ld_rows(rh1, lrow, H1P, 16 * t + 4 * q);
             }
             // ---- dW3~ += dml * h2^T   (owner: wave w -> out tile w>>2, in tile w&3)
             if (!ABLE(2)) __syncthreads();
