@@ -365,6 +365,55 @@ def test_device_mask_and_normal_draws():
     assert abs((e ** 4).mean().item() - 3.0) < 0.05
 
 
+def test_device_mask_draw_ragged_and_unaligned():
+    """The keep-mask kernel serves 8 bytes per Philox call: lengths that are not multiples of 8 and byte-offset
+    (unaligned) views take its scalar tail path and must give the same bits as the vector path for the same counters."""
+    n = 8 * 5000
+    base_in = (torch.rand(n + 16, device=DEV) < 0.8).to(torch.uint8)
+    ref = torch.empty(n, dtype=torch.uint8, device=DEV)
+    vpc.ops.draw_mask(base_in[:n], ref, 0.6, 77, 5)                      # aligned, vector path
+    assert abs(ref.float().sum().item() / base_in[:n].float().sum().item() - 0.6) < 2e-2
+    assert not (ref.bool() & ~base_in[:n].bool()).any()
+    short = torch.empty(n - 3, dtype=torch.uint8, device=DEV)
+    vpc.ops.draw_mask(base_in[:n - 3], short, 0.6, 77, 5)                # ragged tail: last group is scalar
+    assert torch.equal(short, ref[:n - 3])
+    buf_in = torch.zeros(n + 16, dtype=torch.uint8, device=DEV)
+    buf_in[1:n + 1] = base_in[:n]
+    buf_out = torch.zeros(n + 16, dtype=torch.uint8, device=DEV)
+    vpc.ops.draw_mask(buf_in[1:n + 1], buf_out[1:n + 1], 0.6, 77, 5)     # both pointers off by one byte: scalar path
+    assert torch.equal(buf_out[1:n + 1], ref) and buf_out[0] == 0 and buf_out[n + 1] == 0
+    ones = torch.empty(n, dtype=torch.uint8, device=DEV)
+    vpc.ops.draw_mask(None, ones, 1.0, 1, 0)                             # keep_prob 1 keeps everything, NULL = all ones
+    assert bool(ones.all())
+    vpc.ops.draw_mask(None, ones, 0.0, 1, 0)
+    assert not bool(ones.any())
+
+
+def test_gradient_reduction_forms_agree():
+    """vpc_reduce_step reads the partial blocks in layout order (16 B / lane, inverse index map) when they are 16-byte
+    aligned and falls back to the gather through grad_idx otherwise: same gradients and loss terms up to summation order."""
+    d, B = 128, 1000
+    params = O.init_params(d, L, seed=5)
+    x, mask, mask_p, eq, ep = synth(B, d, seed=99)
+    tr = vpc.FusedTrainer(make_model(vpc.Reg_VAE, d, params))
+    tr.step(x.to(DEV), mask.to(DEV), mask_p.to(DEV), eq.to(DEV), ep.to(DEV), alpha=0.7, beta=0.9, update=False)
+    lay, nb = tr.lay, min(vpc._lib.lib().vpc_num_cus(), (B + 127) // 128)
+    co = tr.coefficients(1, 0.7, 0.9, False)
+    args = (lay.n_enc, tr.loss_part, nb, co["cA"][0], co["cE"][0], co["cA"][1], co["bq"], co["bp"], co["cr"], co["wml"],
+            B, B, d)
+    res = []
+    for shift in (0, 1):  # 1: views that start 4 bytes into a buffer -> not 16-byte aligned -> gather form
+        pe = torch.zeros(tr.partE.numel() + 4, device=DEV)[shift:shift + tr.partE.numel()]
+        pd = torch.zeros(tr.partD.numel() + 4, device=DEV)[shift:shift + tr.partD.numel()]
+        pe.copy_(tr.partE); pd.copy_(tr.partD)
+        assert (pe.data_ptr() % 16 == 0) == (shift == 0)
+        g, o9 = torch.zeros_like(tr.grad), torch.zeros(9, device=DEV)
+        vpc.ops.reduce_step(pe, nb, lay.enc_part, pd, nb, lay.dec_part, tr.gidx, g, *args, o9)
+        res.append((g.cpu().numpy(), o9.cpu().numpy()))
+    assert np.array_equal(res[0][0], tr.grad.cpu().numpy())       # the trainer used the layout-order form
+    assert rel(res[0][0], res[1][0]) < 1e-6 and np.allclose(res[0][1], res[1][1], rtol=1e-6)
+
+
 def test_train_harness_fused_and_api(tmp_path, monkeypatch):
     """train() restated (train.py:13-133): loss decreases, checkpoint lands where model_loader('test') reads it."""
     monkeypatch.chdir(tmp_path)
