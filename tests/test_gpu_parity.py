@@ -294,7 +294,7 @@ def test_fused_step_ragged_shapes_vs_oracle(d, B):
         off += p.numel()
 
 
-@pytest.mark.parametrize("d,B", [(128, 300), (100, 130), (125, 70)])
+@pytest.mark.parametrize("d,B", [(128, 300), (100, 130), (125, 70), (128, 40000), (128, 65536)])
 def test_decoder_kernel_variants_agree(d, B, monkeypatch):
     """d in (64, 128] has two fused decoder kernels (8 waves x 1 row tile - the default - and 4 waves x 2 row tiles,
     VPC_DEC8=0): same arguments, same partial-block layout, results equal up to fp32 summation order."""
