@@ -138,7 +138,8 @@ int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float
  * When both strides are multiples of 4 floats and the block pointers 16-byte aligned (true for the blocks the
  * kernels above write) the blocks are read in layout order, 16 bytes per lane, through an inverse map
  * (block position -> parameter) that the library builds on the first call for a given grad_idx pointer and keeps
- * (one small device allocation per process; not rebuilt inside a stream capture - call once eagerly first).
+ * (up to four such maps - one small device allocation each - are cached per process; none is built inside a stream
+ * capture: call once eagerly first).
  * Summation order is fixed either way (reproducible), but differs between the two forms in the last bits. */
 int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
                     int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,

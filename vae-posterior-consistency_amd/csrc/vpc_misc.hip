@@ -249,25 +249,32 @@ struct InvCache {
     long sE = 0, sD = 0;
     int* inv = nullptr;  // [sE | sD]
 };
-static InvCache g_inv;
+static InvCache g_inv[4];  // a few layouts may be live at once (several models in one process); round-robin eviction
+static int g_inv_next = 0;
 // returns the device maps, or false when they cannot be used (unaligned operands) or built right now (stream capture)
 static bool inverse_maps(const int* grad_idx, int n_enc, int n, const float* pe, long sE, const float* pd, long sD,
                          hipStream_t s, const int** invE, const int** invD) {
     if ((sE & 3) || (sD & 3) || !aligned16(pe) || !aligned16(pd)) return false;
-    if (g_inv.key != grad_idx || g_inv.n_enc != n_enc || g_inv.n != n || g_inv.sE != sE || g_inv.sD != sD) {
+    InvCache* hit = nullptr;
+    for (InvCache& e : g_inv)
+        if (e.inv && e.key == grad_idx && e.n_enc == n_enc && e.n == n && e.sE == sE && e.sD == sD) hit = &e;
+    if (!hit) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
-        if (g_inv.inv) (void)hipFree(g_inv.inv);
-        g_inv = InvCache{};
+        InvCache& e = g_inv[g_inv_next];
+        g_inv_next = (g_inv_next + 1) % 4;
+        if (e.inv) (void)hipFree(e.inv);  // synchronises the device: no launch still reads the evicted map
+        e = InvCache{};
         int* buf = nullptr;
         if (hipMalloc(&buf, sizeof(int) * (size_t)(sE + sD)) != hipSuccess) return false;
         hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)((sE + sD + 255) / 256)), dim3(256), 0, s, buf, sE + sD);
         hipLaunchKernelGGL(inv_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, grad_idx, buf, buf + sE, n_enc, n);
         if (hipGetLastError() != hipSuccess) { (void)hipFree(buf); return false; }
-        g_inv.key = grad_idx; g_inv.n_enc = n_enc; g_inv.n = n; g_inv.sE = sE; g_inv.sD = sD; g_inv.inv = buf;
+        e.key = grad_idx; e.n_enc = n_enc; e.n = n; e.sE = sE; e.sD = sD; e.inv = buf;
+        hit = &e;
     }
-    *invE = g_inv.inv;
-    *invD = g_inv.inv + sE;
+    *invE = hit->inv;
+    *invD = hit->inv + sE;
     return true;
 }
 
