@@ -206,7 +206,8 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     // Staging is full width (all 128 batch rows of the workgroup tile at once): ONE write + barrier + read round per
-    // wgrad, 6 barriers per pass instead of 12 (barriers were 16 % of this kernel, `profiles/r01_notes.md`).  That
+    // wgrad round (two rounds: layer 2, then layers 1 + 3 together), 4 barriers per pass instead of 12 (barriers were 16 %
+    // of this kernel, `profiles/r01_notes.md`).  That
     // fits in LDS because the B operand of the layer-1 wgrad - x * mask, the only use of x in this kernel - never
     // goes through LDS: a B fragment wants batch rows along the register index and features along the lanes, which
     // is how row-major x lies in memory, so the tile's owner wave reads it from global memory directly.
@@ -292,22 +293,8 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) h1[t] = ld_rows(rh1, lrow, H1P, 16 * t + 4 * q);
             }
-            // ---- dW3~ += dml * h2^T   (owner: wave w -> out tile w>>2, in tile w&3)
-            if (!ABLE(2)) __syncthreads();
-            if (!ABLE(1)) {
-                stage_write_b<CH>(stA, 0, dml[0], sb);
-                stage_write_b<CH>(stA, 1, dml[1], sb);
-#pragma unroll
-                for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
-            }
-            if (!ABLE(2)) __syncthreads();
-#pragma unroll
-            for (int s = 0; s < CH / 16; ++s) {
-                const f32x4 fa = stage_frag<CH>(stA, w >> 2, s, cc, qq);
-                const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
-            }
+            // (dW3~ += dml * h2^T is staged and computed together with the layer-1 wgrad below: the B staging buffer is
+            // free in that round because x never goes through LDS - 4 instead of 6 barriers per pass)
             VPC_STAMP(1);
             // ---- dh2 = relu'(h2) * (W3~^T dml)
             launder(cc, qq);
@@ -370,8 +357,20 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             if (!ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
+                // operands of dW3~ (owner: wave w -> out tile w>>2, in tile w&3): h2 -> stB tiles 0..3, dml -> stB tiles 4, 5
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
+                stage_write_b<CH>(stB, H2T, dml[0], sb);
+                stage_write_b<CH>(stB, H2T + 1, dml[1], sb);
             }
             if (!ABLE(2)) __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const f32x4 fa = stage_frag<CH>(stB, H2T + (w >> 2), s, cc, qq);
+                const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
+            }
             if (w < DT && !ABLE(4)) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
