@@ -423,6 +423,12 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
         for (int k = 0; k < WAVES; ++k) t += db1s[k * 128 + threadIdx.x];
         a.part[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = t;
     }
+#ifdef VPC_ABLATE
+    VPC_STAMP(6);
+    if (ABLE(64) && blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 3 == 0)
+        printf("enc_bwd blk %d wave %d cycles: top %llu loads %llu dh2 %llu dW2 %llu dh1 %llu dW1+dW3 %llu epilogue %llu\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6]);
+#endif
 }
 
 static size_t enc_fwd_lds(int DT) { return sizeof(float) * EncImg(DT).total; }
