@@ -288,7 +288,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     VPC_CUT();
                     dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
                 }
-                // ---------------- dW5~ += dg2 * g1^T   (owner: wave w < 7 -> out tile w; 4 in tiles)
+                // ---------------- dW5~ += dg2 * g1^T   (28 tiles; owners below)
                 VPC_STAMP(5);
                 VPC_CUT();
                 launder(cc, qq);
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     g1b[0][mt] = relu4(acc[0]);
                 }
                 const uint32_t gm1 = relu_bits<H2T>(g1b[0]);
+                const int nt5 = w & 3, mt5 = 4 * (w >> 2);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     if (!ABL(2)) __syncthreads();
@@ -311,19 +312,25 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1b[0][t], sb);
                     }
                     if (!ABL(2)) __syncthreads();
-                    if (own5 && !ABL(4)) {
+                    // owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3; out tile 7 does not exist, so waves 4..7
+                    // run three: 7 tiles on every SIMD (waves s and s + 4) instead of 8 / 8 / 8 / 4 with one wave per out tile
+                    if (!ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
-                            const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
-                            f32x4 fb_cur = stage_frag<CH>(stB, 0, s, cc, qq);
+                            const f32x4 fb = stage_frag<CH>(stB, nt5, s, cc, qq);
+                            f32x4 fa_cur = stage_frag<CH>(stA, mt5, s, cc, qq);
 #pragma unroll
-                            for (int nt = 0; nt < H2T; ++nt) {
-                                const f32x4 fb_nxt = stage_frag<CH>(stB, nt + 1 < H2T ? nt + 1 : nt, s, cc, qq);
+                            for (int i = 0; i < 3; ++i) {
+                                const f32x4 fa_nxt = stage_frag<CH>(stA, mt5 + i + 1, s, cc, qq);  // mt5 + 3 = 7: unused rows of stA
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc5[nt] = VPC_MFMA(fa[j], fb_cur[j], acc5[nt]);
-                                fb_cur = fb_nxt;
+                                for (int j = 0; j < 4; ++j) acc5[i] = VPC_MFMA(fa_cur[j], fb[j], acc5[i]);
+                                fa_cur = fa_nxt;
+                            }
+                            if (w < 4) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc5[3] = VPC_MFMA(fa_cur[j], fb[j], acc5[3]);
                             }
                         }
                     }
@@ -438,10 +445,13 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = 0.f;
     }
+    // dW5 tile (mt = 4 hi + i, nt = w & 3) sits in acc5[i] (see the wgrad-5 loop) and belongs to wave slot mt & 3 = i
 #pragma unroll
-    for (int nt = 0; nt < H2T; ++nt)
+    for (int i = 0; i < 4; ++i) {
+        float* p5 = a.part + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(56 + 16 * hi + 4 * nt + j) * 64] = own5 ? acc5[nt][j] : 0.f;
+        for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
+    }
     if (own4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
