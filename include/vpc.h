@@ -8,7 +8,8 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer unless the comment says "host"; the caller owns all buffers, the
- *    library allocates nothing and keeps no state between calls (thread-safe by statelessness);
+ *    library allocates no device memory and keeps no state between calls except two per-device caches of constants
+ *    (CU count, "dynamic-LDS attribute already raised for this kernel"), both mutex / atomic protected;
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every launch goes on it;
  *  - return value: 0 ok, 1 bad argument, 2 unsupported shape (d > 128 or L > 15), 3 HIP runtime error.
  *    No exceptions cross the ABI;
@@ -60,10 +61,12 @@ int vpc_reduce_partials(const float* partials, int nblocks, long block_stride, c
 /* torch.optim.Adam(lr, betas, eps), no weight decay / amsgrad - src/experiment_main/train.py:21,116.
  * `step` is the 1-based step count; if step_dev != NULL the count is read from device memory instead (word 0
  * of the `state` vpc_reduce_step maintains) so that a captured HIP graph can be replayed.  If pack_idx/img are
- * non-NULL the updated value is also written into the packed image (saves the vpc_pack_weights launch). */
+ * non-NULL the updated value is also written into the packed image (saves the vpc_pack_weights launch).
+ * accum != NULL: accum[0] += loss_in[0] in the same launch (data parallel: the epoch total of the all-reduced step
+ * loss, train.py:117, without a separate tiny kernel). */
 int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
                   float beta1, float beta2, float eps, long step, const long long* step_dev, const int* pack_idx,
-                  float* img, void* stream);
+                  float* img, const float* loss_in, float* accum, void* stream);
 
 /* ---- encoder: Reg_VAE.encoder / vanilla_VAE.encoder, src/models/VAE.py:387-395, 1155-1163 -------- */
 
@@ -135,14 +138,16 @@ int vpc_loss_finalize(const double* loss_partials, int nblocks, float cA0, float
  * decoder blocks (grad_idx as returned by vpc_build_indices), out9 / accum as vpc_loss_finalize.  If state != NULL
  * (two int64 words on the device) the kernel also does state[0] += 1 (optimiser step count) and
  * state[1] += rng_inc (Philox counter offset): the per-step counters of a replayed HIP graph.
- * When both strides are multiples of 4 floats and the block pointers 16-byte aligned (true for the blocks the
- * kernels above write) the blocks are read in layout order, 16 bytes per lane, through an inverse map
- * (block position -> parameter) that the library builds on the first call for a given grad_idx pointer and keeps
- * (up to four such maps - one small device allocation each - are cached per process; none is built inside a stream
- * capture: call once eagerly first).
+ * inv_maps (optional): the inverse maps (block position -> parameter) vpc_build_inverse_maps wrote for this
+ * grad_idx.  With them - and both strides multiples of 4 floats and the block pointers 16-byte aligned, true for the
+ * blocks the kernels above write - the blocks are read in layout order, 16 bytes per lane, instead of 4-byte
+ * gathers through grad_idx.  The library allocates nothing and keeps no state: the caller owns the map buffer.
  * Summation order is fixed either way (reproducible), but differs between the two forms in the last bits. */
+int vpc_build_inverse_maps(const int* grad_idx, int n_enc, int n, long enc_stride, long dec_stride, int* inv_out,
+                           void* stream); /* inv_out: enc_stride + dec_stride ints (device) */
 int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
-                    int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                    int dec_blocks, long dec_stride, const int* grad_idx, const int* inv_maps, float* grad_out,
+                    int n_enc, int n,
                     const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq, float bp,
                     float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
                     long long* state, long long rng_inc, void* stream);
@@ -151,28 +156,40 @@ int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, 
  * finishes gradient i updates parameter i (and its packed-image entry) on the spot.  Same result as the two
  * calls in sequence; `step` >= 1 is the optimiser step count of THIS update. */
 int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
-                         int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                         int dec_blocks, long dec_stride, const int* grad_idx, const int* inv_maps, float* grad_out,
+                         int n_enc, int n,
                          const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
                          float bp, float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
                          float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, long step, const int* pack_idx, float* img, void* stream);
 
-/* ---- random draws (Philox4x32-10, counter = element index + offset) ------------------------------- */
+/* ---- random draws (Philox4x32-10, counter = GLOBAL element-group index + offset) -------------------
+ * Data parallel: a rank that holds rows [row_lo, row_lo + B_local) of a global batch passes
+ * where its shard starts, and every element gets the counter it would get in the single-process run on the
+ * concatenated batch - the drawn mask_p / eps of a row do not depend on the world size. */
 
 /* mask_out = mask_in AND (U < keep_prob): create_missing_uci(shape, rate) * mask with keep_prob = 1 - rate/100
  * (src/utils/utils.py:36-39, src/experiment_main/train.py:53-55).  mask_in NULL = all ones.  U has 16 random
- * bits (one Philox call serves 8 elements; element i uses counter i / 8 + offset): keep_prob is resolved to 2^-16. */
+ * bits (one Philox call serves 8 elements; element i uses counter (elem_lo + i) / 8 + offset): keep_prob is resolved
+ * to 2^-16.  elem_lo = index of mask_out[0] in the global array (row_lo * d; 0 for a single process). */
 int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob, unsigned long long seed,
-                  unsigned long long offset, void* stream);
+                  unsigned long long offset, long elem_lo, void* stream);
 
 /* vpc_draw_mask + vpc_fill_normal in one launch (the two per-step draws of the fused step).  If state != NULL,
- * state[1] (device) is added to both offsets. */
+ * state[1] (device) is added to both offsets.  mask_elem_lo as vpc_draw_mask's elem_lo; eps_* as vpc_fill_normal's
+ * row-shard arguments. */
 int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out, long n_eps,
                   unsigned long long seed, unsigned long long offset_mask, unsigned long long offset_eps,
-                  const long long* state, void* stream);
+                  const long long* state, long mask_elem_lo, long eps_rows_local, long eps_rows_global,
+                  long eps_row_lo, int eps_pitch, void* stream);
 
-/* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392). */
-int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);
+/* out ~ N(0,1): the eps of Normal.rsample() (VAE.py:389-392); one Philox call per 4 floats.  state (optional,
+ * device): state[1] is added to the offset (the per-step counter of a replayed HIP graph, as vpc_draw_step).
+ * rows_local == 0: flat array, group g uses counter g + offset.  rows_local > 0: out is [planes][rows_local][pitch]
+ * (pitch % 4 == 0), the rows [row_lo, row_lo + rows_local) of a global [planes][rows_global][pitch] array, and a
+ * group uses the counter of its position in the global array. */
+int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, const long long* state,
+                    long rows_local, long rows_global, long row_lo, int pitch, void* stream);
 
 /* ---- active variable selection reward (config 5) -------------------------------------------------------
  * Replaces the candidate loop of active_learning_func (src/experiment_main/evaluate.py:424-433) and the
@@ -248,10 +265,13 @@ int vpc_nm_loss(const float* x, const float* mask, const float* mask_p, const fl
  * create_missing_uci * mask, train.py:53-55; Philox counter = element index / 4 + offset), xin[0:B] = x * mask and,
  * when mask_p_out != NULL, xin[B:2B] = x * mask_p (the two encoder passes stacked); when n_eps > 0 also
  * eps_out[0:n_eps] ~ N(0,1) (counter offset_eps).  If state != NULL, state[1] (device) is added to both offsets:
- * the per-step counter of a replayed HIP graph (bumped by vpc_nm_loss). */
+ * the per-step counter of a replayed HIP graph (bumped by vpc_nm_loss).  elem_lo (multiple of 4) = index of x[0] in
+ * the global [B_global][d] array and eps_* = row-shard description of eps_out as in vpc_fill_normal (rows = data rows,
+ * pitch = K * L): the draws of a row do not depend on the data-parallel sharding. */
 int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin, long B, int d, float keep_prob,
                 float* eps_out, long n_eps, unsigned long long seed, unsigned long long offset,
-                unsigned long long offset_eps, const long long* state, void* stream);
+                unsigned long long offset_eps, const long long* state, long elem_lo, long eps_rows_local,
+                long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream);
 
 /* ---- PNP / EDDI encoder front-end (Reg_EDDI / vanilla_EDDI, src/models/VAE.py:719-733, 903-917) ----------
  * agg[b] = sum_j mask[b][j] relu(W [x_bj, x_bj E_j, t_j] + c), W = pnp_encoder1.0.weight [K][2+K], c its bias,

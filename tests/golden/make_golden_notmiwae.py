@@ -4,10 +4,10 @@
 
 Authoring container only: imports /root/reference (never copied, never shipped) and stores DATA only.
 
-  nm_reg_d{14,40}.npz      REG_notMIWAE_v2 (VAE.py:2327-2505): state_dict, inputs (x, float masks), the eps the two
+  nm_reg_d{14,40,128}.npz  REG_notMIWAE_v2 (VAE.py:2327-2505): state_dict, inputs (x, float masks), the eps the two
                            rsample() calls drew, the 8 forward outputs, loss for alpha in {1.0, 0.5, 0.0} with all
                            parameter grads, the llh_eval branch (xm, RE_q.mean())
-  nm_van_d{14,40}.npz      notMIWAE_myversion (VAE.py:2691-2847): same, incl. the fresh eps drawn inside loss()
+  nm_van_d{14,40,128}.npz  notMIWAE_myversion (VAE.py:2691-2847): same, incl. the fresh eps drawn inside loss()
   nm_traj_{reg,van}_d14.npz  5 Adam steps exactly as train.py:87-117 runs them
   nm_eval_{reg,van}_d14.npz  (--eval) the reference's eval_vae_mnar (evaluate.py:13-69) on a checkpoint in its own
                            naming scheme: parameters, test rows and the RMSE it wrote
@@ -60,7 +60,7 @@ def make_inputs(B, d, seed):
     return x, mask, mask_p
 
 
-def gen_reg(d, L, K, B, seed):
+def gen_reg(d, L, K, B, seed, alphas=(1.0, 0.5, 0.0)):
     torch.manual_seed(seed)
     model = REG_notMIWAE_v2(d, 500, 10, L, TP, K, 1)
     x, mask, mask_p = make_inputs(B, d, seed + 1)
@@ -68,7 +68,7 @@ def gen_reg(d, L, K, B, seed):
     out.update(x=x.numpy(), mask=mask.numpy(), mask_p=mask_p.numpy(), K=np.int64(K), L=np.int64(L))
     eps_q, eps_p = peek_normals([(B, K, L), (B, K, L)])
     names = ["mean_p", "logvar_p", "x_mean_p", "x_logvar_p", "mean_q", "logvar_q", "x_mean_q", "x_logvar_q"]
-    for alpha in (1.0, 0.5, 0.0):
+    for alpha in alphas:
         st = torch.get_rng_state()
         model.zero_grad()
         outs = model.forward(x, mask, mask_p, "train")
@@ -209,3 +209,7 @@ if __name__ == "__main__":
     gen_van(40, 6, 5, 24, 42)
     gen_traj("reg")
     gen_traj("van")
+    # config 3's own model shape (UCI gas, d = 128, K = train_k = 20, imputation_args_mnar.json), B kept small: the
+    # fixture stores [B, K, d] outputs and every gradient
+    gen_reg(128, 10, 20, 8, 33, alphas=(0.5,))
+    gen_van(128, 10, 20, 8, 43)

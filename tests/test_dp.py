@@ -1,4 +1,4 @@
-"""Data-parallel path: world_size-2 process groups over gloo on 127.0.0.1.
+"""Data-parallel path: process groups over gloo on 127.0.0.1 (world_size 2, 4 and 8).
 
 * CPU test: the bucket contract of dist.py - every rank contributes grads / loss terms of its row shard
   normalised by the GLOBAL batch; one all_reduce(SUM) equals the single-process result on the concatenated
@@ -64,12 +64,12 @@ def _cpu_worker(rank, world, port, d, B, out):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("d,B", [(14, 37), (128, 64)])
-def test_bucket_allreduce_equals_single_process_gloo(d, B):
+@pytest.mark.parametrize("d,B,world", [(14, 37, 2), (128, 64, 2), (128, 203, 8)])
+def test_bucket_allreduce_equals_single_process_gloo(d, B, world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, d, B, out)) for r in range(2)]
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, d, B, out)) for r in range(world)]
     for p in procs:
         p.start()
     got = out.get(timeout=120)
@@ -94,7 +94,7 @@ def test_shard_rows_partition():
 
 
 # ----------------------------------------------------------------------------------------------- GPU, 2 ranks
-def _gpu_worker(rank, world, port, d, B, steps, out):
+def _gpu_worker(rank, world, port, d, B, steps, out, device_draws=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     vpc.dp.init_from_env(backend="gloo")
@@ -104,16 +104,19 @@ def _gpu_worker(rank, world, port, d, B, steps, out):
     sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
     m.to(dev)
     vpc.dp.broadcast_parameters(m.flatten_parameters())
-    tr = vpc.FusedTrainer(m, world_size=world)
+    tr = vpc.FusedTrainer(m, world_size=world, rank=rank)
     x, mask, mask_p, eq, ep = _inputs(B, d)
     lo, hi = vpc.dp.shard_rows(B, rank, world)
     losses = []
     for i in range(steps):
-        tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eq[lo:hi].to(dev), ep[lo:hi].to(dev),
-                alpha=0.8, beta=0.9, epoch=i + 1, global_batch=B)
+        if device_draws:  # mask_p / eps from the shared-seed Philox stream, counters keyed by the GLOBAL row
+            tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), alpha=0.8, beta=0.9, epoch=i + 1, global_batch=B, row_lo=lo)
+        else:
+            tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eq[lo:hi].to(dev), ep[lo:hi].to(dev),
+                    alpha=0.8, beta=0.9, epoch=i + 1, global_batch=B, row_lo=lo)
         losses.append(tr.loss_value())
     if rank == 0:
-        out.put((losses, m._flat.cpu().numpy()))
+        out.put((losses, m._flat.cpu().numpy(), tr.epoch_total()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -127,22 +130,87 @@ def test_two_rank_fused_trainer_matches_single_process():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, d, B, steps, out)) for r in range(2)]
     for p in procs:
         p.start()
-    losses2, flat2 = out.get(timeout=300)
+    losses2, flat2, total2 = out.get(timeout=300)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
     dev = torch.device("cuda:0")
-    params = O.init_params(d, L, seed=5)
-    m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
-    sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
-    m.to(dev)
-    tr = vpc.FusedTrainer(m)
+    tr, m = _single_trainer(d, B, dev)
     x, mask, mask_p, eq, ep = _inputs(B, d)
     for i in range(steps):
         tr.step(x.to(dev), mask.to(dev), mask_p.to(dev), eq.to(dev), ep.to(dev), alpha=0.8, beta=0.9, epoch=i + 1)
         assert abs(tr.loss_value() - losses2[i]) <= 2e-6 * abs(losses2[i])
     flat1 = m._flat.cpu().numpy()
     assert np.max(np.abs(flat1 - flat2)) <= 2e-6 * np.max(np.abs(flat1))
+    # the epoch total every rank reports is the GLOBAL one (sum of the all-reduced step losses)
+    assert abs(tr.epoch_total() - total2) <= 1e-5 * abs(total2)
+
+
+def _single_trainer(d, B, dev, seed=0):
+    params = O.init_params(d, L, seed=5)
+    m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
+    sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
+    m.to(dev)
+    return vpc.FusedTrainer(m, seed=seed), m
+
+
+@pytest.mark.gpu
+def test_four_rank_device_draws_match_single_process():
+    """World size 4 over gloo (the GPU box admits at most 6 GPU processes: 4 ranks + this one), mask_p and eps drawn ON
+    THE DEVICE with one shared seed and Philox counters keyed by the global row: losses, the
+    epoch total and the parameters after 3 Adam steps equal the single-process run on the concatenated batch."""
+    d, B, steps, world = 128, 4 * 1024, 3, 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, d, B, steps, out, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses4, flat4, total4 = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    tr, m = _single_trainer(d, B, dev)
+    x, mask, _, _, _ = _inputs(B, d)
+    for i in range(steps):
+        tr.step(x.to(dev), mask.to(dev), alpha=0.8, beta=0.9, epoch=i + 1)
+        assert abs(tr.loss_value() - losses4[i]) <= 5e-6 * abs(losses4[i]), (i, tr.loss_value(), losses4[i])
+    flat1 = m._flat.cpu().numpy()
+    assert np.max(np.abs(flat1 - flat4)) <= 3e-5 * np.max(np.abs(flat1))
+    assert abs(tr.epoch_total() - total4) <= 1e-5 * abs(total4)
+
+
+@pytest.mark.gpu
+def test_eight_shards_of_the_headline_batch_match_single_process():
+    """Config 4's decomposition, B = 65 536 sharded 8 x 8 192, with device-side draws.  Eight
+    GPU processes do not fit the box's process limit, so the eight ranks run one after the other in this process:
+    each is a FusedTrainer with its own rank / row_lo, the shared seed and global_batch = 65 536, and the all-reduce
+    is a sum of the eight buckets.  Checks (i) every shard draws exactly the mask_p bytes and eps values the
+    single-process step draws for those rows (bit-equal: the result does not depend on the world size) and (ii) the
+    summed bucket [grads | loss terms] equals the single-process bucket."""
+    d, B, world = 128, 65536, 8
+    dev = torch.device("cuda:0")
+    x, mask, _, _, _ = _inputs(B, d, seed=11)
+    x, mask = x.to(dev), mask.to(dev)
+    tr1, _ = _single_trainer(d, B, dev, seed=7)
+    tr1.step(x, mask, alpha=0.8, beta=0.9, update=False)
+    want = tr1.bucket.clone()
+    mp1, eps1 = tr1.mask_p_buf.clone(), tr1.eps_buf[:2].clone()
+    assert 0.45 < float(mp1.float().mean()) < 0.53  # 0.7 * 0.7
+    total = torch.zeros_like(want, dtype=torch.float64)
+    for r in range(world):
+        lo, hi = vpc.dp.shard_rows(B, r, world)
+        trr, _ = _single_trainer(d, B, dev, seed=7)
+        trr.rank = r
+        trr.step(x[lo:hi], mask[lo:hi], alpha=0.8, beta=0.9, update=False, global_batch=B, row_lo=lo)
+        assert torch.equal(trr.mask_p_buf, mp1[lo:hi]), r
+        assert torch.equal(trr.eps_buf[:2], eps1[:, lo:hi]), r
+        total += trr.bucket.double()
+    n = tr1.lay.n_params
+    g1, g8 = want[:n].double(), total[:n]
+    assert float((g1 - g8).abs().max()) <= 2e-5 * float(g1.abs().max())
+    assert abs(float(want[n]) - float(total[n])) <= 2e-6 * abs(float(want[n]))
 
 
 # ----------------------------------------------------------------------------------------------- MNAR path, 2 ranks
@@ -167,16 +235,16 @@ def _nm_gpu_worker(rank, world, port, d, B, K, Ld, steps, out):
     dev = torch.device("cuda:0")
     m = _nm_model(d, K, Ld, B).to(dev)
     vpc.dp.broadcast_parameters(m.flatten_parameters())
-    tr = vpc.NMTrainer(m, world_size=world)
+    tr = vpc.NMTrainer(m, world_size=world, rank=rank)
     x, mask, mask_p, eps = _nm_inputs(B, d, K, Ld)
     lo, hi = vpc.dp.shard_rows(B, rank, world)
     losses = []
     for i in range(steps):
         tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eps[:, lo:hi].contiguous().to(dev),
-                alpha=0.5, global_batch=B)
+                alpha=0.5, global_batch=B, row_lo=lo)
         losses.append(tr.loss_value())
     if rank == 0:
-        out.put((losses, m._flat.cpu().numpy()))
+        out.put((losses, m._flat.cpu().numpy(), tr.epoch_total()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -192,7 +260,7 @@ def test_two_rank_mnar_trainer_matches_single_process():
     procs = [ctx.Process(target=_nm_gpu_worker, args=(r, 2, port, d, B, K, Ld, steps, out)) for r in range(2)]
     for p in procs:
         p.start()
-    losses2, flat2 = out.get(timeout=300)
+    losses2, flat2, total2 = out.get(timeout=300)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -207,6 +275,7 @@ def test_two_rank_mnar_trainer_matches_single_process():
     # sharding changes the fp32 summation order of the weight gradients; Adam's m / sqrt(v) turns a 1e-7 relative
     # difference of a tiny gradient into up to lr = 1e-3 per step, so parameters are compared at 3e-5 of their scale
     assert np.max(np.abs(flat1 - flat2)) <= 3e-5 * np.max(np.abs(flat1))
+    assert abs(tr.epoch_total() - total2) <= 1e-5 * abs(total2)  # every rank's epoch total is the global loss
 
 
 # ----------------------------------------------------------------------------------------------- EDDI family, 2 ranks
@@ -230,13 +299,13 @@ def _eddi_gpu_worker(rank, world, port, d, B, K, Ld, steps, out):
     dev = torch.device("cuda:0")
     m = _eddi_model(d, K, Ld, B).to(dev)
     vpc.dp.broadcast_parameters(m.flatten_parameters())
-    tr = vpc.EDDITrainer(m, world_size=world)
+    tr = vpc.EDDITrainer(m, world_size=world, rank=rank)
     x, mask, mask_p, eq, ep = _eddi_inputs(B, d, Ld)
     lo, hi = vpc.dp.shard_rows(B, rank, world)
     losses = []
     for i in range(steps):
         tr.step(x[lo:hi].to(dev), mask[lo:hi].to(dev), mask_p[lo:hi].to(dev), eq[lo:hi].to(dev), ep[lo:hi].to(dev),
-                epoch=i + 1, alpha=0.5, global_batch=B)
+                epoch=i + 1, alpha=0.5, global_batch=B, row_lo=lo)
         losses.append(tr.loss_value())
     if rank == 0:
         out.put((losses, m._flat.cpu().numpy()))

@@ -202,6 +202,44 @@ def test_fused_trainer_trajectory(ed, kind):
     _close(xhat, ref, 2e-5, "decoder after fused steps")
 
 
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_fused_trainer_d128_vs_oracle(ed, kind):
+    """EDDITrainer at d = 128 (UCI gas width; the shape that goes through dec8_kernel<8>), K = 20, B = 200 against the
+    EDDI oracle's torch port (pinned to the reference by eddi_*.npz): loss 1e-4 relative, all 16 gradients 2e-4 of max.
+    Reference: src/models/VAE.py:719-741 (front-end), :403-467 / :935-950 (loss)."""
+    from oracle import eddi_oracle as EO
+    d, K, Ld, B = 128, 20, 10, 200
+    torch.manual_seed(31)
+    if kind == "reg":
+        model = ed.Reg_EDDI(d, 500, K, Ld, {"batch_size": B, "patience": 1}, "exp", "kl_reg")
+    else:
+        model = ed.vanilla_EDDI(d, 500, K, Ld, {"batch_size": B, "patience": 1}, "exp")
+    p = {k: v.detach().clone().float().requires_grad_(True) for k, v in model.state_dict().items() if k in EO.EDDI_KEYS}
+    model = model.cuda()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, d, generator=g)
+    m = torch.rand(B, d, generator=g) < 0.7
+    mp = m & (torch.rand(B, d, generator=g) < 0.7)
+    eq, ep = torch.randn(B, Ld, generator=g), torch.randn(B, Ld, generator=g)
+    port = EO.EDDIPort(p, Ld, "kl_reg")
+    if kind == "reg":
+        o = port.reg_forward(x, m, mp, eq, ep)
+        _, ref = port.reg_loss(x, o[2], o[3], o[0], o[1], o[6], o[7], o[4], o[5], m, mp, 1, alpha=0.5, beta=1.0)
+    else:
+        o = port.vanilla_forward(x, m, eq)
+        _, ref = port.vanilla_loss(x, o[2], o[3], o[0], o[1], 1, m)
+    ref.backward()
+    tr = ed.EDDITrainer(model, lr=1e-3)
+    if kind == "reg":
+        tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda(), eps_q=eq.cuda(), eps_p=ep.cuda(), epoch=1, alpha=0.5)
+    else:
+        tr.step(x.cuda(), m.cuda(), eps_q=eq.cuda(), epoch=1)
+    assert abs(tr.loss_value() - ref.item()) <= 1e-4 * abs(ref.item()), (tr.loss_value(), ref.item())
+    for k, prm in model.named_parameters():
+        if k in p:
+            _close(prm.grad, p[k].grad, 2e-4, f"grad {k}")
+
+
 def test_fused_trainer_device_draws(ed):
     torch.manual_seed(2)
     B, d, K = 256, 100, 20

@@ -231,6 +231,38 @@ def test_fused_step_grads_match_golden(d, tag, kw):
         off += p.numel()
 
 
+@pytest.mark.parametrize("d", [14, 128])
+def test_fused_vanilla_step_grads_match_golden(d):
+    """vanilla_VAE on the FUSED step against the reference's own vectors (loss_b1 + all 12 gradients).  d = 128 is
+    the shape that runs dec8_kernel / enc_*_kernel<8> with npass == 1 (one pass, no second mask, no KL coupling);
+    d = 14 runs the 4-wave decoder.  Reference: src/models/VAE.py:1171-1208 + autograd."""
+    g = vpc_golden(f"vanilla_d{d}.npz")
+    m = make_model(vpc.vanilla_VAE, d, golden_params(g))
+    tr = vpc.FusedTrainer(m)
+    tr.step(_t(g["x"]), _t(g["mask"]), eps_q=_t(g["eps_q"]), beta=1.0, epoch=1, update=False)
+    want = float(g["loss_b1"])
+    assert abs(tr.loss_value() - want) <= 2e-5 * abs(want)
+    flat = tr.grad.cpu().numpy()
+    off = 0
+    for k, p in zip(O.PARAM_KEYS, m.trainable()):
+        got = flat[off:off + p.numel()].reshape(p.shape)
+        assert rel(got, g[f"b1.grad.{k}"]) < 2e-4, k
+        off += p.numel()
+    # and at a batch that fills several workgroup tiles, against the oracle's port (same shape class)
+    B = 700
+    params = O.init_params(d, L, seed=21)
+    x, mask, _, eq, _ = synth(B, d, seed=5)
+    loss_ref, grads_ref, _ = O.torch_vanilla_step(params, L, x, mask, eq)
+    m2 = make_model(vpc.vanilla_VAE, d, params)
+    tr2 = vpc.FusedTrainer(m2)
+    tr2.step(x.to(DEV), mask.to(DEV), eps_q=eq.to(DEV), update=False)
+    assert abs(tr2.loss_value() - loss_ref.item()) <= 2e-5 * abs(loss_ref.item())
+    flat, off = tr2.grad.cpu().numpy(), 0
+    for k, p in zip(O.PARAM_KEYS, m2.trainable()):
+        assert rel(flat[off:off + p.numel()].reshape(p.shape), grads_ref[k].numpy()) < 2e-4, k
+        off += p.numel()
+
+
 @pytest.mark.parametrize("kind", ["reg", "vanilla"])
 def test_fused_adam_trajectory_matches_golden(kind):
     g = vpc_golden(f"traj_{kind}_d14.npz")
@@ -390,8 +422,9 @@ def test_device_mask_draw_ragged_and_unaligned():
 
 
 def test_gradient_reduction_forms_agree():
-    """vpc_reduce_step reads the partial blocks in layout order (16 B / lane, inverse index map) when they are 16-byte
-    aligned and falls back to the gather through grad_idx otherwise: same gradients and loss terms up to summation order."""
+    """vpc_reduce_step reads the partial blocks in layout order (16 B / lane) when the caller passes the inverse maps
+    of vpc_build_inverse_maps and the blocks are 16-byte aligned, and gathers through grad_idx otherwise (no map, or
+    unaligned blocks): same gradients and loss terms up to summation order."""
     d, B = 128, 1000
     params = O.init_params(d, L, seed=5)
     x, mask, mask_p, eq, ep = synth(B, d, seed=99)
@@ -402,15 +435,18 @@ def test_gradient_reduction_forms_agree():
     args = (lay.n_enc, tr.loss_part, nb, co["cA"][0], co["cE"][0], co["cA"][1], co["bq"], co["bp"], co["cr"], co["wml"],
             B, B, d)
     res = []
-    for shift in (0, 1):  # 1: views that start 4 bytes into a buffer -> not 16-byte aligned -> gather form
-        pe = torch.zeros(tr.partE.numel() + 4, device=DEV)[shift:shift + tr.partE.numel()]
-        pd = torch.zeros(tr.partD.numel() + 4, device=DEV)[shift:shift + tr.partD.numel()]
+    for shift in (0, 1, 2):  # 1: views that start 4 bytes into a buffer -> not 16-byte aligned -> gather form; 2: no map
+        sh = shift & 1
+        pe = torch.zeros(tr.partE.numel() + 4, device=DEV)[sh:sh + tr.partE.numel()]
+        pd = torch.zeros(tr.partD.numel() + 4, device=DEV)[sh:sh + tr.partD.numel()]
         pe.copy_(tr.partE); pd.copy_(tr.partD)
-        assert (pe.data_ptr() % 16 == 0) == (shift == 0)
+        assert (pe.data_ptr() % 16 == 0) == (sh == 0)
         g, o9 = torch.zeros_like(tr.grad), torch.zeros(9, device=DEV)
-        vpc.ops.reduce_step(pe, nb, lay.enc_part, pd, nb, lay.dec_part, tr.gidx, g, *args, o9)
+        vpc.ops.reduce_step(pe, nb, lay.enc_part, pd, nb, lay.dec_part, tr.gidx, g, *args, o9,
+                            inv_maps=None if shift == 2 else tr.inv)
         res.append((g.cpu().numpy(), o9.cpu().numpy()))
     assert np.array_equal(res[0][0], tr.grad.cpu().numpy())       # the trainer used the layout-order form
+    assert np.array_equal(res[1][0], res[2][0])                    # both gather runs
     assert rel(res[0][0], res[1][0]) < 1e-6 and np.allclose(res[0][1], res[1][1], rtol=1e-6)
 
 
@@ -480,19 +516,26 @@ def test_eval_vae_matches_oracle(kind, tmp_path, monkeypatch):
         assert os.path.exists(pth)
 
 
-def test_graph_replay_matches_eager_steps():
+@pytest.mark.parametrize("cls", ["Reg_VAE", "vanilla_VAE"])
+def test_graph_replay_matches_eager_steps(cls):
     """FusedTrainer.step_graph (captured HIP graph, device-side step / RNG counters) == the same steps run eagerly:
-    identical Philox streams, identical Adam bias corrections."""
+    identical Philox streams, identical Adam bias corrections.  vanilla_VAE draws its eps through vpc_fill_normal,
+    which reads the counter offset from the device `state` too: a replay must not repeat the captured noise."""
     d, B = 14, 64
     params = O.init_params(d, L, seed=9)
     x, mask, _, _, _ = synth(B, d, seed=4)
     xd, md = x.to(DEV), mask.to(DEV)
-    m1, m2 = make_model(vpc.Reg_VAE, d, params), make_model(vpc.Reg_VAE, d, params)
+    C = getattr(vpc, cls)
+    m1, m2 = make_model(C, d, params), make_model(C, d, params)
     t1, t2 = vpc.FusedTrainer(m1, seed=3), vpc.FusedTrainer(m2, seed=3)
+    seen = []
     for i in range(6):
         t1.step(xd, md, alpha=0.9, beta=0.8)
         t2.step_graph(xd, md, alpha=0.9, beta=0.8)
         assert abs(t1.loss_value() - t2.loss_value()) <= 1e-6 * abs(t1.loss_value()), i
+        assert torch.equal(t1.eps_buf[0], t2.eps_buf[0]), i
+        seen.append(t2.eps_buf[0].clone())
+    assert all(not torch.equal(a, b) for a, b in zip(seen, seen[1:]))  # fresh noise on every replay
     assert torch.equal(m1._flat, m2._flat)
     assert abs(t1.epoch_total() - t2.epoch_total()) < 1e-3
     # new inputs are copied into the captured buffers

@@ -30,6 +30,43 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), name
 
 
+_CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+          "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong}
+
+
+def _ctype_of(param: str):
+    """C parameter declaration -> the ctypes class _lib._PROTOS must use for it."""
+    param = re.sub(r"/\*.*?\*/", "", param).strip()
+    if "*" in param:
+        if param.count("*") == 2:
+            return ctypes.POINTER(ctypes.c_void_p)
+        base = re.sub(r"\bconst\b", "", param.split("*")[0]).strip()
+        return {"int": ctypes.POINTER(ctypes.c_int), "long": ctypes.POINTER(ctypes.c_long)}.get(base, ctypes.c_void_p)
+    words = re.sub(r"\bconst\b", "", param).split()
+    return _CTYPE[" ".join(words[:-1])]  # drop the parameter name
+
+
+def test_ctypes_prototypes_match_the_header():
+    """Argument count AND type of every entry of _lib._PROTOS against the declaration in include/vpc.h (a drifted
+    int / long / float would pass the symbol test and corrupt arguments at run time).  The .hip definitions are checked
+    against the same header by the compiler: every translation unit includes it (vpc_abi_internal.h)."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vpc.h")).read(), flags=re.S)
+    decls = re.findall(r"\b(int|long)\s+(vpc_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    assert len(decls) == len(vpc._lib._PROTOS)
+    for ret, name, params in decls:
+        params = " ".join(params.split())
+        want = [] if params in ("", "void") else [_ctype_of(p) for p in params.split(",")]
+        got = vpc._lib._PROTOS[name]
+        assert len(got) == len(want), (name, len(got), len(want))
+        for i, (g, w) in enumerate(zip(got, want)):
+            ok = g is w or (w is ctypes.c_void_p and g in (ctypes.c_void_p,)) or \
+                (g is ctypes.POINTER(ctypes.c_float) and w is ctypes.c_void_p)  # host float arrays (cA / cE)
+            if w in (ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long)) and g is ctypes.c_void_p:
+                ok = True  # int / long arrays passed as raw pointers
+            assert ok, (name, i, g, w)
+        assert (ret == "long") == (name in vpc._lib._RESTYPE_LONG), name
+
+
 def test_bad_arguments_are_rejected_without_gpu():
     l = vpc._lib.lib()
     assert l.vpc_layout_sizes(129, 10, 0, *[None] * 8) == 2
@@ -37,7 +74,10 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert l.vpc_layout_sizes(14, 16, 0, *[None] * 8) == 2
     assert l.vpc_layout_sizes(14, 10, 0, *[None] * 8) == 0
     assert l.vpc_encoder_fwd(None, None, 1, None, None, None, None, None, None, None, 10, 0, 4, 14, 10, None) == 1
-    assert l.vpc_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None, None, None, None) == 1
+    assert l.vpc_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None, None, None, None, None, None) == 1
+    assert l.vpc_build_inverse_maps(None, 1, 2, 4, 4, None, None) == 1
+    assert l.vpc_draw_mask(None, None, 8, 0.5, 0, 0, 0, None) == 1
+    assert l.vpc_fill_normal(None, 8, 0, 0, None, 0, 0, 0, 4, None) == 1
     # MNAR path: null pointers / bad shapes are rejected before anything touches the device
     assert l.vpc_linear_fwd(None, 4, None, None, None, 4, 8, 4, 4, 0, 0, None) == 1
     assert l.vpc_linear_dgrad(None, 4, None, 4, 0, 0, None, None, 4, 0, None, 4, 8, 4, 4, None) == 1

@@ -37,7 +37,7 @@ _PROTOS = {
     "vpc_num_cus": [],
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
-    "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P, P],
+    "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P, P, P, P],
     "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, L_, I, I, P],
     "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
@@ -47,12 +47,14 @@ _PROTOS = {
     "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, P,
                           P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
-    "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, C.c_longlong, P],
-    "vpc_reduce_step_adam": [P, I, L_, P, I, L_, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, P, P, F, F, F,
-                             F, L_, P, P, P],
-    "vpc_draw_mask": [P, P, L_, F, ULL, ULL, P],
-    "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, P],
-    "vpc_fill_normal": [P, L_, ULL, ULL, P],
+    "vpc_build_inverse_maps": [P, I, I, L_, L_, P, P],
+    "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, C.c_longlong,
+                        P],
+    "vpc_reduce_step_adam": [P, I, L_, P, I, L_, P, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, P, P, F, F,
+                             F, F, L_, P, P, P],
+    "vpc_draw_mask": [P, P, L_, F, ULL, ULL, L_, P],
+    "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, L_, L_, L_, L_, I, P],
+    "vpc_fill_normal": [P, L_, ULL, ULL, P, L_, L_, L_, I, P],
     "vpc_reward_scratch": [I, I, I, C.POINTER(L_), C.POINTER(L_), C.POINTER(L_)],
     "vpc_reward_matrix": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     # MNAR path (config 3)
@@ -67,7 +69,7 @@ _PROTOS = {
     "vpc_nm_loss_scratch": [L_, I],
     "vpc_nm_loss": [P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, P, P, P, L_, P, P, L_, P, P, L_, P, P, I, P, P, L_, P,
                     P, P, P, C.c_longlong, I, L_, L_, I, I, I, C.c_double, P],
-    "vpc_nm_prep": [P, P, P, P, L_, I, F, P, L_, ULL, ULL, ULL, P, P],
+    "vpc_nm_prep": [P, P, P, P, L_, I, F, P, L_, ULL, ULL, ULL, P, L_, L_, L_, L_, I, P],
     # PNP / EDDI encoder front-end
     "vpc_eddi_fold": [P, P, P, P, P, I, I, P],
     "vpc_eddi_front_fwd": [P, P, P, P, P, L_, I, I, P],
@@ -157,6 +159,19 @@ class Layout:
         key = str(device)
         if key not in self._dev:
             self._dev[key] = (torch.from_numpy(self.pack_idx).to(device), torch.from_numpy(self.grad_idx).to(device))
+        return self._dev[key]
+
+    def inverse_maps(self, device):
+        """Caller-owned inverse maps (partial-block position -> flat parameter, -1 = padding) for the layout-order
+        gradient reduction of vpc_reduce_step: [enc_part | dec_part] int32 on `device`, built once per device by the
+        explicit entry point vpc_build_inverse_maps (the library itself allocates nothing)."""
+        key = ("inv", str(device))
+        if key not in self._dev:
+            _, gidx = self.device_tables(device)
+            inv = torch.empty(self.enc_part + self.dec_part, dtype=torch.int32, device=device)
+            check(lib().vpc_build_inverse_maps(ptr(gidx), self.n_enc, self.n_params, self.enc_part, self.dec_part,
+                                               ptr(inv), stream_ptr()), "vpc_build_inverse_maps")
+            self._dev[key] = inv
         return self._dev[key]
 
     def nblocks(self, B: int, ncu: int) -> int:

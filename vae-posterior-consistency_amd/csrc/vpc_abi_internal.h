@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+// every translation unit that defines a vpc_* entry point sees its declaration: hipcc rejects a definition whose
+// signature drifted from the header (conflicting types for an extern "C" function)
+#include "../../include/vpc.h"
 
 #define VPC_OK 0
 #define VPC_ERR_ARG 1     // null / misaligned pointer, bad count

@@ -6,31 +6,41 @@
 #include "vpc_abi_internal.h"
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <map>
 #include <mutex>
-#include <unordered_map>
+#include <utility>
 
 namespace vpc {
 
+// CU count of the CURRENT device (one process may drive several devices: cached per device id)
 int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < MAXDEV) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
     }
-    return n;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    if (dev >= 0 && dev < MAXDEV) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device function attribute: remembered per (device, kernel)
 bool lds_attr_done(const void* kern, size_t lds) {
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> seen;
+    static std::map<std::pair<int, const void*>, size_t> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> g(mu);
-    auto it = seen.find(kern);
+    const auto key = std::make_pair(dev, kern);
+    auto it = seen.find(key);
     if (it != seen.end() && it->second >= lds) return true;
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-    seen[kern] = lds;
+    seen[key] = lds;
     return true;
 }
 
@@ -101,8 +111,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
 __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
                             float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, const int* __restrict__ pack_idx, float* __restrict__ img,
-                            const long long* __restrict__ step_dev) {
+                            const long long* __restrict__ step_dev, const float* __restrict__ loss_in,
+                            float* __restrict__ accum) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && accum) accum[0] += loss_in[0];  // epoch total of the (all-reduced) step loss, train.py:117
     if (i >= n) return;
     if (step_dev) {  // graph replay: the step count lives on the device (kernel arguments are frozen)
         const double t = (double)step_dev[0];
@@ -231,8 +243,8 @@ __global__ __launch_bounds__(256) void reduce_step_v2_kernel(const float* __rest
         }
     }
 }
-// inverse maps (block position -> flat parameter index, -1 for padding), built on first use for a given grad_idx and
-// kept for the life of the process (one layout per model; a new grad_idx pointer or shape rebuilds them)
+// inverse maps (block position -> flat parameter index, -1 for padding): built by the explicit entry point
+// vpc_build_inverse_maps into a caller-owned buffer [enc_stride | dec_stride] ints (the library keeps no state)
 __global__ void inv_fill_kernel(int* __restrict__ inv, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) inv[i] = -1;
@@ -243,39 +255,9 @@ __global__ void inv_scatter_kernel(const int* __restrict__ idx, int* __restrict_
     if (i >= n) return;
     if (i < n_enc) invE[idx[i]] = i; else invD[idx[i]] = i;
 }
-struct InvCache {
-    const int* key = nullptr;
-    int n_enc = 0, n = 0;
-    long sE = 0, sD = 0;
-    int* inv = nullptr;  // [sE | sD]
-};
-static InvCache g_inv[4];  // a few layouts may be live at once (several models in one process); round-robin eviction
-static int g_inv_next = 0;
-// returns the device maps, or false when they cannot be used (unaligned operands) or built right now (stream capture)
-static bool inverse_maps(const int* grad_idx, int n_enc, int n, const float* pe, long sE, const float* pd, long sD,
-                         hipStream_t s, const int** invE, const int** invD) {
-    if ((sE & 3) || (sD & 3) || !aligned16(pe) || !aligned16(pd)) return false;
-    InvCache* hit = nullptr;
-    for (InvCache& e : g_inv)
-        if (e.inv && e.key == grad_idx && e.n_enc == n_enc && e.n == n && e.sE == sE && e.sD == sD) hit = &e;
-    if (!hit) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
-        InvCache& e = g_inv[g_inv_next];
-        g_inv_next = (g_inv_next + 1) % 4;
-        if (e.inv) (void)hipFree(e.inv);  // synchronises the device: no launch still reads the evicted map
-        e = InvCache{};
-        int* buf = nullptr;
-        if (hipMalloc(&buf, sizeof(int) * (size_t)(sE + sD)) != hipSuccess) return false;
-        hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)((sE + sD + 255) / 256)), dim3(256), 0, s, buf, sE + sD);
-        hipLaunchKernelGGL(inv_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, grad_idx, buf, buf + sE, n_enc, n);
-        if (hipGetLastError() != hipSuccess) { (void)hipFree(buf); return false; }
-        e.key = grad_idx; e.n_enc = n_enc; e.n = n; e.sE = sE; e.sD = sD; e.inv = buf;
-        hit = &e;
-    }
-    *invE = hit->inv;
-    *invD = hit->inv + sE;
-    return true;
+// the layout-order reduction needs 16-byte vector access to the blocks
+static bool inv_usable(const int* inv, const float* pe, long sE, const float* pd, long sD) {
+    return inv && !(sE & 3) && !(sD & 3) && aligned16(pe) && aligned16(pd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,14 +392,17 @@ __device__ __forceinline__ float u01(uint32_t u) { return ((u >> 8) + 0.5f) * (1
 // One Philox call serves 8 mask bytes: each 32-bit word gives two 16-bit uniforms (keep probability resolved to
 // 2^-16, far below the sampling noise of any batch).
 constexpr int MASK_PER_CALL = 8;
+// `elem_lo` = index of this call's first element inside the GLOBAL array (data parallel: shard_lo * d): the Philox
+// counter of an element is its global index / 8 + offset, so the drawn mask does not depend on how rows are sharded
 __device__ __forceinline__ void draw_mask_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
-                                               float keep_prob, uint64_t seed, uint64_t offset, long g) {
-    const long i0 = g * MASK_PER_CALL;
+                                               float keep_prob, uint64_t seed, uint64_t offset, long g, long elem_lo) {
+    const long G = (elem_lo >> 3) + g;           // global group
+    const long i0 = G * MASK_PER_CALL - elem_lo;  // local index of its first element (negative: group starts in the previous shard)
     if (i0 >= n) return;
-    const U4 r = philox((uint64_t)g + offset, 0u, seed);
+    const U4 r = philox((uint64_t)G + offset, 0u, seed);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
     const uint32_t thr = (uint32_t)(keep_prob * 65536.f + 0.5f);
-    if (i0 + MASK_PER_CALL - 1 < n && (((uintptr_t)in | (uintptr_t)out) & 7u) == 0) {
+    if (i0 >= 0 && i0 + MASK_PER_CALL - 1 < n && ((((uintptr_t)in + (uintptr_t)i0) | ((uintptr_t)out + (uintptr_t)i0)) & 7u) == 0) {
         uint32_t u[2] = {0x01010101u, 0x01010101u}, o[2] = {0u, 0u};
         if (in) {
             const uint2 v = *reinterpret_cast<const uint2*>(in + i0);
@@ -431,6 +416,7 @@ __device__ __forceinline__ void draw_mask_body(const uint8_t* __restrict__ in, u
         *reinterpret_cast<uint2*>(out + i0) = make_uint2(o[0], o[1]);
     } else {
         for (int j = 0; j < MASK_PER_CALL && i0 + j < n; ++j) {
+            if (i0 + j < 0) continue;
             const uint32_t h = (rr[j >> 1] >> (16 * (j & 1))) & 0xffffu;
             out[i0 + j] = ((in ? in[i0 + j] : 1) && h < thr) ? 1 : 0;
         }
@@ -438,15 +424,26 @@ __device__ __forceinline__ void draw_mask_body(const uint8_t* __restrict__ in, u
 }
 
 __global__ void draw_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long n,
-                                 float keep_prob, uint64_t seed, uint64_t offset) {
-    draw_mask_body(in, out, n, keep_prob, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x);
+                                 float keep_prob, uint64_t seed, uint64_t offset, long elem_lo) {
+    draw_mask_body(in, out, n, keep_prob, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x, elem_lo);
+}
+
+// Row-sharded normal draws: `out` is [planes][rows_local][pitch] (pitch % 4 == 0), the local shard of a global
+// [planes][rows_global][pitch] array starting at row row_lo; the Philox counter of a 4-float group is its GLOBAL group
+// index + offset, so every row gets the same eps whatever the sharding.  rows_local == 0: flat array, counter = g + offset.
+struct EpsShard { long rows_local, rows_global, row_lo; int pitch; };
+__device__ __forceinline__ uint64_t eps_counter(const EpsShard& sh, long g) {
+    if (sh.rows_local == 0) return (uint64_t)g;
+    const long gpr = sh.pitch >> 2, gpp = sh.rows_local * gpr;  // groups per row / per local plane
+    const long k = g / gpp, rem = g - k * gpp;
+    return (uint64_t)((k * sh.rows_global + sh.row_lo) * gpr + rem);
 }
 
 __device__ __forceinline__ void fill_normal_body(float* __restrict__ out, long n, uint64_t seed, uint64_t offset,
-                                                 long g) {
+                                                 long g, const EpsShard& sh) {
     const long i0 = g * 4;
     if (i0 >= n) return;
-    const U4 r = philox((uint64_t)g + offset, 1u, seed);
+    const U4 r = philox(eps_counter(sh, g) + offset, 1u, seed);
     // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32 and v_sin / v_cos_f32, whose argument is in
     // revolutions - exactly the uniform.  (-2 ln u = -2 ln2 log2 u.)
     const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));
@@ -457,16 +454,20 @@ __device__ __forceinline__ void fill_normal_body(float* __restrict__ out, long n
     const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
     for (int j = 0; j < 4 && i0 + j < n; ++j) out[i0 + j] = v[j];
 }
-__global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
-    fill_normal_body(out, n, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void fill_normal_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset,
+                                   const long long* __restrict__ state, EpsShard sh) {
+    if (state) offset += (uint64_t)state[1];
+    fill_normal_body(out, n, seed, offset, (long)blockIdx.x * blockDim.x + threadIdx.x, sh);
 }
 // both per-step draws of the fused step in one launch: blocks [0, gm) draw the keep-mask, the rest the normals
 __global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ mout, long nm, float keep_prob,
                                  float* __restrict__ eout, long ne, uint64_t seed, uint64_t off_mask,
-                                 uint64_t off_eps, unsigned gm, const long long* __restrict__ state) {
+                                 uint64_t off_eps, unsigned gm, const long long* __restrict__ state, long elem_lo,
+                                 EpsShard sh) {
     if (state) { off_mask += (uint64_t)state[1]; off_eps += (uint64_t)state[1]; }
-    if (blockIdx.x < gm) draw_mask_body(in, mout, nm, keep_prob, seed, off_mask, (long)blockIdx.x * blockDim.x + threadIdx.x);
-    else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
+    if (blockIdx.x < gm)
+        draw_mask_body(in, mout, nm, keep_prob, seed, off_mask, (long)blockIdx.x * blockDim.x + threadIdx.x, elem_lo);
+    else fill_normal_body(eout, ne, seed, off_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x, sh);
 }
 
 // fused MNAR step: float mask_p draw + the stacked encoder input [x*mask ; x*mask_p] (blocks [0, gm)) and the
@@ -474,12 +475,13 @@ __global__ void draw_step_kernel(const uint8_t* __restrict__ in, uint8_t* __rest
 __global__ void nm_prep_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ mp,
                                float* __restrict__ xin, long n, float keep_prob, float* __restrict__ eps, long n_eps,
                                uint64_t seed, uint64_t offset, uint64_t offset_eps, unsigned gm,
-                               const long long* __restrict__ state) {
+                               const long long* __restrict__ state, long elem_lo, EpsShard sh) {
     if (state) { offset += (uint64_t)state[1]; offset_eps += (uint64_t)state[1]; }
     if (blockIdx.x >= gm) {
-        fill_normal_body(eps, n_eps, seed, offset_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x);
+        fill_normal_body(eps, n_eps, seed, offset_eps, (long)(blockIdx.x - gm) * blockDim.x + threadIdx.x, sh);
         return;
     }
+    offset += (uint64_t)(elem_lo >> 2);  // counter of a mask group = its index in the GLOBAL [B_global][d] array
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long i0 = g * 4;
     if (i0 >= n) return;
@@ -621,15 +623,16 @@ extern "C" int vpc_reduce_partials(const float* partials, int nblocks, long bloc
 
 extern "C" int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
                              float beta1, float beta2, float eps, long step, const long long* step_dev,
-                             const int* pack_idx, float* img, void* stream) {
+                             const int* pack_idx, float* img, const float* loss_in, float* accum, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || (step < 1 && !step_dev)) return VPC_ERR_ARG;
+    if (accum && !loss_in) return VPC_ERR_ARG;
     if (step < 1) step = 1;
     if ((pack_idx == nullptr) != (img == nullptr)) return VPC_ERR_ARG;
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), pack_idx,
-                       img, step_dev);
+                       img, step_dev, loss_in, accum);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -645,8 +648,19 @@ extern "C" int vpc_loss_finalize(const double* loss_partials, int nblocks, float
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
+extern "C" int vpc_build_inverse_maps(const int* grad_idx, int n_enc, int n, long enc_stride, long dec_stride,
+                                      int* inv_out, void* stream) {
+    if (!grad_idx || !inv_out || n_enc <= 0 || n <= n_enc || enc_stride <= 0 || dec_stride <= 0) return VPC_ERR_ARG;
+    const long tot = enc_stride + dec_stride;
+    hipLaunchKernelGGL(inv_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_out, tot);
+    hipLaunchKernelGGL(inv_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_idx, inv_out,
+                       inv_out + enc_stride, n_enc, n);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
 extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
-                               int dec_blocks, long dec_stride, const int* grad_idx, float* grad_out, int n_enc, int n,
+                               int dec_blocks, long dec_stride, const int* grad_idx, const int* inv_maps,
+                               float* grad_out, int n_enc, int n,
                                const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
                                float bp, float cr, float wml, long B_local, long B_global, int d, float* out9,
                                float* accum, long long* state, long long rng_inc, void* stream) {
@@ -656,9 +670,8 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
         return VPC_ERR_ARG;
     const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
                      1.0 / (double)B_global};
-    const int *invE = nullptr, *invD = nullptr;
-    if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
-                     &invD)) {
+    if (inv_usable(inv_maps, enc_partials, enc_stride, dec_partials, dec_stride)) {
+        const int *invE = inv_maps, *invD = inv_maps + enc_stride;
         const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);
         hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                            enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
@@ -674,7 +687,8 @@ extern "C" int vpc_reduce_step(const float* enc_partials, int enc_blocks, long e
 
 extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_stride,
                                     const float* dec_partials, int dec_blocks, long dec_stride, const int* grad_idx,
-                                    float* grad_out, int n_enc, int n, const double* loss_partials, int loss_blocks,
+                                    const int* inv_maps, float* grad_out, int n_enc, int n,
+                                    const double* loss_partials, int loss_blocks,
                                     float cA0, float cE0, float cA1, float bq, float bp, float cr, float wml,
                                     long B_local, long B_global, int d, float* out9, float* accum, float* params,
                                     float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
@@ -687,9 +701,8 @@ extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, l
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2)};
-    const int *invE = nullptr, *invD = nullptr;
-    if (inverse_maps(grad_idx, n_enc, n, enc_partials, enc_stride, dec_partials, dec_stride, (hipStream_t)stream, &invE,
-                     &invD)) {
+    if (inv_usable(inv_maps, enc_partials, enc_stride, dec_partials, dec_stride)) {
+        const int *invE = inv_maps, *invD = inv_maps + enc_stride;
         const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);
         hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
                            enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
@@ -742,42 +755,56 @@ extern "C" int vpc_loss_fwd_bwd(const float* x, int npass, const float* const* x
 }
 
 extern "C" int vpc_draw_mask(const uint8_t* mask_in, uint8_t* mask_out, long n, float keep_prob,
-                             unsigned long long seed, unsigned long long offset, void* stream) {
-    if (!mask_out || n <= 0) return VPC_ERR_ARG;
-    const long groups = (n + MASK_PER_CALL - 1) / MASK_PER_CALL;
+                             unsigned long long seed, unsigned long long offset, long elem_lo, void* stream) {
+    if (!mask_out || n <= 0 || elem_lo < 0) return VPC_ERR_ARG;
+    const long groups = ((elem_lo & 7) + n + MASK_PER_CALL - 1) / MASK_PER_CALL;
     hipLaunchKernelGGL(draw_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       mask_in, mask_out, n, keep_prob, (uint64_t)seed, (uint64_t)offset);
+                       mask_in, mask_out, n, keep_prob, (uint64_t)seed, (uint64_t)offset, elem_lo);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
 extern "C" int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float keep_prob, float* eps_out,
                              long n_eps, unsigned long long seed, unsigned long long offset_mask,
-                             unsigned long long offset_eps, const long long* state, void* stream) {
-    if (!mask_out || !eps_out || n_mask <= 0 || n_eps <= 0) return VPC_ERR_ARG;
-    const unsigned gm = (unsigned)(((n_mask + MASK_PER_CALL - 1) / MASK_PER_CALL + 255) / 256),
+                             unsigned long long offset_eps, const long long* state, long mask_elem_lo,
+                             long eps_rows_local, long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream) {
+    if (!mask_out || !eps_out || n_mask <= 0 || n_eps <= 0 || mask_elem_lo < 0) return VPC_ERR_ARG;
+    if (eps_rows_local < 0 || (eps_rows_local > 0 && (eps_pitch <= 0 || (eps_pitch & 3) || eps_row_lo < 0 ||
+                                                      eps_row_lo + eps_rows_local > eps_rows_global)))
+        return VPC_ERR_ARG;
+    const unsigned gm = (unsigned)((((mask_elem_lo & 7) + n_mask + MASK_PER_CALL - 1) / MASK_PER_CALL + 255) / 256),
                    ge = (unsigned)(((n_eps + 3) / 4 + 255) / 256);
     hipLaunchKernelGGL(draw_step_kernel, dim3(gm + ge), dim3(256), 0, (hipStream_t)stream, mask_in, mask_out, n_mask,
-                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm, state);
+                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset_mask, (uint64_t)offset_eps, gm, state,
+                       mask_elem_lo, EpsShard{eps_rows_local, eps_rows_global, eps_row_lo, eps_pitch});
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
 extern "C" int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset,
+                               const long long* state, long rows_local, long rows_global, long row_lo, int pitch,
                                void* stream) {
     if (!out || n <= 0) return VPC_ERR_ARG;
+    if (rows_local < 0 || (rows_local > 0 && (pitch <= 0 || (pitch & 3) || row_lo < 0 || row_lo + rows_local > rows_global)))
+        return VPC_ERR_ARG;
     const long groups = (n + 3) / 4;
     hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       out, n, (uint64_t)seed, (uint64_t)offset);
+                       out, n, (uint64_t)seed, (uint64_t)offset, state, EpsShard{rows_local, rows_global, row_lo, pitch});
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
 extern "C" int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin, long B, int d,
                            float keep_prob, float* eps_out, long n_eps, unsigned long long seed,
                            unsigned long long offset, unsigned long long offset_eps, const long long* state,
+                           long elem_lo, long eps_rows_local, long eps_rows_global, long eps_row_lo, int eps_pitch,
                            void* stream) {
     if (!x || !mask || !xin || B <= 0 || d <= 0 || n_eps < 0 || (n_eps > 0 && !eps_out)) return VPC_ERR_ARG;
+    if (elem_lo < 0 || (elem_lo & 3)) return VPC_ERR_ARG;
+    if (eps_rows_local < 0 || (eps_rows_local > 0 && (eps_pitch <= 0 || (eps_pitch & 3) || eps_row_lo < 0 ||
+                                                      eps_row_lo + eps_rows_local > eps_rows_global)))
+        return VPC_ERR_ARG;
     const long n = B * d, groups = (n + 3) / 4, ge = (n_eps + 3) / 4;
     const unsigned gm = (unsigned)((groups + 255) / 256), gn = (unsigned)((ge + 255) / 256);
     hipLaunchKernelGGL(nm_prep_kernel, dim3(gm + gn), dim3(256), 0, (hipStream_t)stream, x, mask, mask_p_out, xin, n,
-                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset, (uint64_t)offset_eps, gm, state);
+                       keep_prob, eps_out, n_eps, (uint64_t)seed, (uint64_t)offset, (uint64_t)offset_eps, gm, state,
+                       elem_lo, EpsShard{eps_rows_local, eps_rows_global, eps_row_lo, eps_pitch});
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }

@@ -39,10 +39,13 @@ def shard_rows(n_rows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_parameters(flat: torch.Tensor, src=0, group=None):
-    """Make every replica start from rank `src`'s weights."""
+def broadcast_parameters(flat: torch.Tensor, src=0, group=None, model=None):
+    """Make every replica start from rank `src`'s weights.  Pass `model` so that its packed weight images are
+    re-packed on the next forward (the flat buffer is written behind the parameters' backs)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+    if model is not None and hasattr(model, "invalidate_images"):
+        model.invalidate_images()
 
 
 def shutdown():

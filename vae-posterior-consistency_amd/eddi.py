@@ -225,7 +225,7 @@ class EDDITrainer:
     materialised) -> trunk backward GEMMs -> front-end backward -> [one all-reduce of [grads | loss terms]] -> flat
     Adam + decoder image re-pack."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0):
         if not isinstance(model, _EDDIBase):
             raise TypeError("EDDITrainer supports Reg_EDDI and vanilla_EDDI")
         from .fused import FusedTrainer
@@ -234,7 +234,7 @@ class EDDITrainer:
         self.coefficients = lambda *a: FusedTrainer.coefficients(self, *a)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.seed, self.rng_offset, self.step_count = seed, 0, 0
-        self.pg, self.world_size = process_group, world_size
+        self.pg, self.world_size, self.rank = process_group, world_size, rank
         self.lay = model._lay()
         flat = model.flatten_parameters()
         L.require_cuda(flat)
@@ -278,7 +278,7 @@ class EDDITrainer:
         self._B = B
 
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=0.5, beta=1.0,
-             beta_annealing=False, p_missingness=30, global_batch=None):
+             beta_annealing=False, p_missingness=30, global_batch=None, row_lo=None):
         m, lay = self.model, self.lay
         d, Ld, K = m.obs_dim, m.latent_dim, m.emb_dim
         x = ops._f32c(x.reshape(-1, d))
@@ -298,19 +298,24 @@ class EDDITrainer:
         need_ml = two and co["wml"] != 0.0
         eps_view = self.eps_buf[: (3 if need_ml else 2 if two else 1)]
         inject = eps_q is not None
+        if row_lo is None:
+            row_lo = self.rank * B if self.world_size > 1 else 0
+        # Philox counters of the GLOBAL row: draws do not depend on the world size
+        eps_shard = (B, Bg, row_lo, LP)
+        n_eps_groups = eps_view.shape[0] * Bg * (LP // 4)
         if two and mask_p is None:
             off_m = self.rng_offset
-            self.rng_offset += (B * d + 3) // 4
+            self.rng_offset += (Bg * d + 7) // 8 + 1  # counters advance by what the GLOBAL batch consumes
             ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
-                          self.rng_offset)
-            self.rng_offset += (eps_view.numel() + 3) // 4
+                          self.rng_offset, None, row_lo * d, eps_shard)
+            self.rng_offset += n_eps_groups
             mask_p = self.mask_p_buf
         else:
             if two:
                 mask_p = as_mask_u8(mask_p.reshape(-1, d))
             if not inject:
-                ops.fill_normal(eps_view, self.seed, self.rng_offset)
-                self.rng_offset += (eps_view.numel() + 3) // 4
+                ops.fill_normal(eps_view, self.seed, self.rng_offset, None, eps_shard)
+                self.rng_offset += n_eps_groups
         if eps_q is not None:
             self.eps_buf[0, :, :Ld].copy_(eps_q)
         if two and eps_p is not None:
@@ -356,10 +361,10 @@ class EDDITrainer:
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
-            self.accum += self.out9[0]
         self.step_count += 1
+        dp = self.world_size > 1  # the Adam launch also adds the all-reduced loss to the epoch accumulator
         ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
-                      self.betas[1], self.eps)
+                      self.betas[1], self.eps, loss_in=self.out9 if dp else None, accum=self.accum if dp else None)
         # keep the packed decoder image in step with the parameters (the version check would re-pack it anyway)
         ops.pack_weights(m._flat[self.n_trunk:self.n_trunk + self.n_dec], self.pidx[lay.n_enc:], m._img)
         m._img_version = m._versions()

@@ -31,7 +31,7 @@ LP = 16  # row pitch of the padded latent workspaces
 
 
 class FusedTrainer:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0):
         if not isinstance(model, (Reg_VAE, vanilla_VAE)):
             raise TypeError("FusedTrainer supports Reg_VAE and vanilla_VAE")
         self.model = model
@@ -42,6 +42,7 @@ class FusedTrainer:
         self.step_count = 0
         self.pg = process_group
         self.world_size = world_size
+        self.rank = rank  # data parallel: this rank's rows are [rank * B, (rank + 1) * B) of the global batch by default
         self.lay = model._lay()
         flat = model.flatten_parameters()
         L.require_cuda(flat)
@@ -59,6 +60,7 @@ class FusedTrainer:
         self.partD = torch.empty(ncu * self.lay.dec_part, device=self.dev)
         self.loss_part = torch.empty(ncu, 8, dtype=torch.float64, device=self.dev)
         self.pidx, self.gidx = self.lay.device_tables(self.dev)
+        self.inv = self.lay.inverse_maps(self.dev)  # caller-owned maps for the layout-order gradient reduction
         self._ws_B = None
         self.timers = None  # bench.py sets this to {} to collect per-kernel HIP event pairs
         self.timer_every = 8  # ... on every 8th step only: an event pair costs ~5 us of GPU idle time per kernel
@@ -115,10 +117,14 @@ class FusedTrainer:
 
     # ------------------------------------------------------------------
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=1.0, beta=1.0,
-             beta_annealing=False, p_missingness=30, global_batch=None, update=True, _state=None):
+             beta_annealing=False, p_missingness=30, global_batch=None, row_lo=None, update=True, _state=None):
         """One training step on the local rows `x` [B, d] (fp32, GPU), `mask` [B, d] (bool / uint8 / float).
         mask_p / eps_* are drawn on the device unless injected (parity tests).  Returns nothing: the loss of
-        this step is in `self.out9[0]` (device), the running total in `self.accum` (train.py:117)."""
+        this step is in `self.out9[0]` (device), the running total in `self.accum` (train.py:117).
+        Data parallel: `global_batch` rows in all (default B * world_size) of which this rank holds
+        [row_lo, row_lo + B) (default rank * B).  The Philox counters of the draws are those of the GLOBAL row
+        (SURVEY.md section 8e): with one shared seed every row gets the mask_p / eps it would get in the single-process
+        step on the concatenated batch, whatever the world size."""
         L.require_cuda(x)
         self._timer_tick += 1
         lay, m = self.lay, self.model
@@ -127,6 +133,10 @@ class FusedTrainer:
         mask = as_mask_u8(mask)
         self._workspaces(B)
         Bg = global_batch if global_batch is not None else B * self.world_size
+        if row_lo is None:
+            row_lo = self.rank * B if self.world_size > 1 else 0
+        if row_lo < 0 or row_lo + B > Bg:
+            raise ValueError(f"rows [{row_lo}, {row_lo + B}) are not inside the global batch of {Bg}")
         co = self.coefficients(epoch, alpha, beta, beta_annealing)
         img = m._images()
         enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
@@ -136,22 +146,25 @@ class FusedTrainer:
         need_ml = two and co["wml"] != 0.0
         draw_eps = eps_q is None or (two and eps_p is None) or (need_ml and eps_ml is None)
         eps_view = self.eps_buf[: (3 if need_ml else 2 if two else 1)]  # only the draws this step consumes
-        n_eps_groups = (eps_view.numel() + 3) // 4
+        # counters advance by what the GLOBAL batch consumes, so that all ranks stay on one stream of counters
+        n_eps_groups = eps_view.shape[0] * Bg * (LP // 4)
+        eps_shard = (B, Bg, row_lo, LP)
         if two and mask_p is None:
             off_m = self.rng_offset
-            self.rng_offset += (B * d + 3) // 4
+            self.rng_offset += (Bg * d + 7) // 8 + 1
             if draw_eps:
                 ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
-                              self.rng_offset, _state)
+                              self.rng_offset, _state, row_lo * d, eps_shard)
                 self.rng_offset += n_eps_groups
                 draw_eps = False
             else:
-                ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, off_m)
+                ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, off_m, row_lo * d)
             mask_p = self.mask_p_buf
         elif two:
             mask_p = as_mask_u8(mask_p)
         if draw_eps:
-            ops.fill_normal(eps_view, self.seed, self.rng_offset)
+            # `_state`: under graph replay the offset lives on the device (a frozen host offset would replay one eps)
+            ops.fill_normal(eps_view, self.seed, self.rng_offset, _state, eps_shard)
             self.rng_offset += n_eps_groups
         if eps_q is not None:  # injected draws (parity tests) arrive dense [B][L]; pad entries are ignored
             self.eps_buf[0, :, :Ld].copy_(eps_q)
@@ -181,21 +194,25 @@ class FusedTrainer:
                         lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
                         cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
                         self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.step_count, self.pidx, img)
+                        self.step_count, self.pidx, img, self.inv)
             return
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part,
                     self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"],
                     co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9,
                     self.accum if self.world_size == 1 else None, _state,
-                    self.rng_offset - rng0 if _state is not None else 0)
+                    self.rng_offset - rng0 if _state is not None else 0, self.inv)
         if self.world_size > 1:
             self._allreduce()
-            self.accum += self.out9[0]
         if update:
             self.step_count += 1
+            # under data parallelism the Adam launch also adds the all-reduced loss to the epoch accumulator
             ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                         self.lr, self.betas[0], self.betas[1], self.eps, self.pidx, img,
-                        None if _state is None else _state[0:1])
+                        None if _state is None else _state[0:1],
+                        loss_in=self.out9 if self.world_size > 1 else None,
+                        accum=self.accum if self.world_size > 1 else None)
+        elif self.world_size > 1:
+            self.accum += self.out9[0]
 
     # ------------------------------------------------------------------ HIP-graph replay of the step
     def step_graph(self, x, mask, *, epoch=1, alpha=1.0, beta=1.0, beta_annealing=False, p_missingness=30):

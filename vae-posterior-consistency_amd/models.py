@@ -106,7 +106,16 @@ class _VAEBase(nn.Module):
         return self._flat
 
     def _versions(self):
-        return tuple(p._version for p in self.trainable()) + (self.seq_encoder[0].weight.data_ptr(),)
+        """What the packed image was built from: the version counters of the 12 parameters AND of the flat buffer they
+        are views of (an in-place write through `_flat` - dist.broadcast, a raw kernel - bumps only the latter).  Writes
+        through `p.data` bump neither: call invalidate_images() after those."""
+        flat = getattr(self, "_flat", None)
+        return tuple(p._version for p in self.trainable()) + (self.seq_encoder[0].weight.data_ptr(),
+                                                               -1 if flat is None else flat._version)
+
+    def invalidate_images(self):
+        """Force a re-pack of the weight images on the next forward (after writing parameters through `.data`)."""
+        self._img_version = None
 
     def _images(self):
         """Packed weight images [enc | dec], re-packed when any parameter changed (in-place version counters)."""

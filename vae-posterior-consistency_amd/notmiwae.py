@@ -70,10 +70,13 @@ def nm_mul(x, mask, out):
     check(lib().vpc_nm_mul(ptr(x), ptr(mask), ptr(out), out.numel(), stream_ptr()), "vpc_nm_mul")
 
 
-def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, eps_out=None, offset_eps=0, state=None):
+def nm_prep(x, mask, mask_p_out, xin, B, d, keep_prob, seed, offset, eps_out=None, offset_eps=0, state=None,
+            elem_lo=0, eps_shard=None):
+    """eps_shard = (rows_local, rows_global, row_lo, pitch) of eps_out as rows of a global batch (None: flat)."""
+    sh = (0, 0, 0, 4) if eps_shard is None else tuple(int(v) for v in eps_shard)
     check(lib().vpc_nm_prep(ptr(x), ptr(mask), ptr(mask_p_out), ptr(xin), B, d, float(keep_prob), ptr(eps_out),
                             0 if eps_out is None else eps_out.numel(), int(seed), int(offset), int(offset_eps),
-                            ptr(state), stream_ptr()), "vpc_nm_prep")
+                            ptr(state), int(elem_lo), *sh, stream_ptr()), "vpc_nm_prep")
 
 
 def nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, hq, hp, W, b, eps_kl, g_xm_q, g_xl_q, g_xm_p, g_xl_p,
@@ -503,13 +506,13 @@ class NMTrainer:
     both passes), the fused loss kernel, the backward GEMM chain writing straight into one flat gradient buffer,
     one all-reduce of [grads | loss] under data parallelism, flat Adam."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0):
         if not isinstance(model, _NMBase):
             raise TypeError("NMTrainer supports REG_notMIWAE_v2 and notMIWAE_myversion")
         self.model, self.reg = model, model.regularised
         self.lr, self.betas, self.eps_adam = lr, betas, eps
         self.seed, self.rng_offset, self.step_count = seed, 0, 0
-        self.pg, self.world_size = process_group, world_size
+        self.pg, self.world_size, self.rank = process_group, world_size, rank
         flat = model.flatten_parameters()
         L.require_cuda(flat)
         self.dev = flat.device
@@ -560,9 +563,12 @@ class NMTrainer:
         self.timers.setdefault(name, []).append((e0, e1))
         return r
 
-    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30, global_batch=None, _state=None):
+    def step(self, x, mask, mask_p=None, eps=None, *, alpha=1.0, p_missingness=30, global_batch=None, row_lo=None,
+             _state=None):
         """One optimiser step.  mask_p / eps ([2, B, K, L]: (eps_q, eps_p) or (eps, eps_kl)) may be injected for
-        parity tests; otherwise they are drawn on the device (one launch: mask_p + stacked encoder input + normals)."""
+        parity tests; otherwise they are drawn on the device (one launch: mask_p + stacked encoder input + normals).
+        Data parallel: this rank holds rows [row_lo, row_lo + B) (default rank * B) of `global_batch` rows; the Philox
+        counters are those of the global row, so the draws do not depend on the world size."""
         m = self.model
         v = m._views()
         d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
@@ -575,7 +581,13 @@ class NMTrainer:
         P = 2 if reg else 1
         R, M, BK = P * B, P * B * K, B * K
         t = self._t
-        rng_inc = (2 * B * K * Ld + 3) // 4 + (B * d + 3) // 4
+        if row_lo is None:
+            row_lo = self.rank * B if self.world_size > 1 else 0
+        rng_inc = (2 * Bg * K * Ld + 3) // 4 + (Bg * d + 3) // 4 + 1  # what the GLOBAL batch consumes
+        sharded = (row_lo * d) % 4 == 0 and (K * Ld) % 4 == 0
+        # shapes whose shards do not start on a Philox group: per-rank counter streams instead of global-row counters
+        rank_off = 0 if sharded else (self.rank << 44)
+        eps_shard = (B, Bg, row_lo, K * Ld) if sharded else None
         # ---- inputs
         if reg and mask_p is not None:
             mp = _f32c(mask_p.reshape(-1, d))
@@ -583,11 +595,12 @@ class NMTrainer:
             nm_mul(xf, mp, self.xin[B:])
             if eps is None:
                 from .ops import fill_normal
-                fill_normal(self.eps, self.seed, self.rng_offset + (1 << 40))
+                fill_normal(self.eps, self.seed, self.rng_offset + (1 << 40) + rank_off, _state, eps_shard)
         else:
             mp = self.mask_p if reg else None
-            t("prep", nm_prep, xf, mf, mp, self.xin, B, d, 1.0 - p_missingness / 100.0, self.seed, self.rng_offset,
-              self.eps if eps is None else None, self.rng_offset + (1 << 40), _state)
+            t("prep", nm_prep, xf, mf, mp, self.xin, B, d, 1.0 - p_missingness / 100.0, self.seed,
+              self.rng_offset + rank_off, self.eps if eps is None else None, self.rng_offset + (1 << 40) + rank_off,
+              _state, row_lo * d if sharded else 0, eps_shard)
         if eps is not None:
             self.eps.copy_(eps)
         self.rng_offset += rng_inc
@@ -604,8 +617,9 @@ class NMTrainer:
         t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
           self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
           G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
-          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss, self.accum, B, Bg, K, d, Ld, alpha,
-          _state, rng_inc, True)
+          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss,
+          self.accum if self.world_size == 1 else None,  # data parallel: the epoch total takes the ALL-REDUCED loss (below)
+          B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
         # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
         g = self.g
         t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID)
@@ -627,7 +641,8 @@ class NMTrainer:
         self.step_count += 1
         from .ops import adam_step
         t("adam", adam_step, m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-          self.betas[0], self.betas[1], self.eps_adam, None, None, None if _state is None else _state[0:1])
+          self.betas[0], self.betas[1], self.eps_adam, None, None, None if _state is None else _state[0:1],
+          loss_in=self.loss if self.world_size > 1 else None, accum=self.accum if self.world_size > 1 else None)
 
     def step_graph(self, x, mask, *, alpha=1.0, p_missingness=30):
         """The same step replayed from a captured HIP graph (torch.cuda.CUDAGraph): ONE host call instead of ~30

@@ -43,9 +43,10 @@ def reduce_partials(partials, nblocks, stride, grad_idx, out, scale=1.0):
 
 
 def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, pack_idx=None, img=None,
-              step_dev=None):
+              step_dev=None, loss_in=None, accum=None):
     check(lib().vpc_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), lr, beta1, beta2, eps,
-                              int(step), ptr(step_dev), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_adam_step")
+                              int(step), ptr(step_dev), ptr(pack_idx), ptr(img), ptr(loss_in), ptr(accum),
+                              stream_ptr()), "vpc_adam_step")
 
 
 def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None, mask_augm=False):
@@ -108,34 +109,43 @@ def loss_finalize(loss_part, nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B
 
 
 def reduce_step(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq, bp,
-                cr, wml, B_local, B_global, d, out9, accum=None, state=None, rng_inc=0):
-    check(lib().vpc_reduce_step(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(grad), n_enc,
+                cr, wml, B_local, B_global, d, out9, accum=None, state=None, rng_inc=0, inv_maps=None):
+    check(lib().vpc_reduce_step(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(inv_maps),
+                                ptr(grad), n_enc,
                                 grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d,
                                 ptr(out9), ptr(accum), ptr(state), int(rng_inc), stream_ptr()), "vpc_reduce_step")
 
 
 def reduce_step_adam(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq,
                      bp, cr, wml, B_local, B_global, d, out9, accum, params, m, v, lr, beta1, beta2, eps, step, pack_idx,
-                     img):
-    check(lib().vpc_reduce_step_adam(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(grad),
-                                     n_enc, grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local,
+                     img, inv_maps=None):
+    check(lib().vpc_reduce_step_adam(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(inv_maps),
+                                     ptr(grad), n_enc, grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local,
                                      B_global, d, ptr(out9), ptr(accum), ptr(params), ptr(m), ptr(v), lr, beta1, beta2,
                                      eps, int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_reduce_step_adam")
 
 
-def draw_mask(mask_in, mask_out, keep_prob, seed, offset):
+def draw_mask(mask_in, mask_out, keep_prob, seed, offset, elem_lo=0):
+    """elem_lo: index of mask_out[0] inside the global [B_global, d] array (data parallel: row_lo * d)."""
     check(lib().vpc_draw_mask(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), int(seed), int(offset),
-                              stream_ptr()), "vpc_draw_mask")
+                              int(elem_lo), stream_ptr()), "vpc_draw_mask")
 
 
-def draw_step(mask_in, mask_out, keep_prob, eps_out, seed, offset_mask, offset_eps, state=None):
+def _shard4(shard):
+    """(rows_local, rows_global, row_lo, pitch) of a row-sharded eps array, or the flat form."""
+    return (0, 0, 0, 4) if shard is None else tuple(int(v) for v in shard)
+
+
+def draw_step(mask_in, mask_out, keep_prob, eps_out, seed, offset_mask, offset_eps, state=None, elem_lo=0,
+              eps_shard=None):
     check(lib().vpc_draw_step(ptr(mask_in), ptr(mask_out), mask_out.numel(), float(keep_prob), ptr(eps_out),
-                              eps_out.numel(), int(seed), int(offset_mask), int(offset_eps), ptr(state), stream_ptr()),
-          "vpc_draw_step")
+                              eps_out.numel(), int(seed), int(offset_mask), int(offset_eps), ptr(state), int(elem_lo),
+                              *_shard4(eps_shard), stream_ptr()), "vpc_draw_step")
 
 
-def fill_normal(out, seed, offset):
-    check(lib().vpc_fill_normal(ptr(out), out.numel(), int(seed), int(offset), stream_ptr()), "vpc_fill_normal")
+def fill_normal(out, seed, offset, state=None, shard=None):
+    check(lib().vpc_fill_normal(ptr(out), out.numel(), int(seed), int(offset), ptr(state), *_shard4(shard),
+                                stream_ptr()), "vpc_fill_normal")
 
 
 # ------------------------------------------------------------------------------------------------ autograd
