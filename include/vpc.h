@@ -46,8 +46,11 @@ int vpc_layout_sizes(int d, int L, int mask_augm, int* enc_img_floats, int* dec_
  * img_template[enc_img_floats + dec_img_floats] (zeros plus the constant ones of the bias chain). */
 int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int* grad_idx, float* img_template);
 
-/* Compute units of the current device = maximum number of workgroups (partial blocks) any kernel uses. */
+/* Compute units of the current device. */
 int vpc_num_cus(void);
+/* Upper bound of *nblocks_out of any kernel below (= 2 * CUs: the small-batch shape spreads the two passes over
+ * separate workgroups): size `partials` / `loss_partials` buffers for this many blocks. */
+int vpc_max_partial_blocks(void);
 
 /* ---- parameters --------------------------------------------------------------------------------- */
 

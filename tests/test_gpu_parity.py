@@ -17,6 +17,18 @@ TP = {"batch_size": 64, "patience": 100}
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True, params=["auto", "tile128"])
+def tile_shape(request, monkeypatch):
+    """Every test of this module runs twice: with the library's own choice of workgroup shape (for these batch sizes
+    the small-batch shape: 64-row tiles, 4 waves, passes spread over blockIdx.y) and with the throughput shape forced
+    (VPC_TILE=128: 128-row tiles, 8 waves, passes looped) - csrc/vpc_abi_internal.h `tile_shape`."""
+    if request.param == "tile128":
+        monkeypatch.setenv("VPC_TILE", "128")
+    else:
+        monkeypatch.delenv("VPC_TILE", raising=False)
+    return request.param
+
+
 def _t(a, dev=DEV):
     return torch.from_numpy(np.array(a)).to(dev)
 
@@ -326,6 +338,34 @@ def test_fused_step_ragged_shapes_vs_oracle(d, B):
         off += p.numel()
 
 
+@pytest.mark.parametrize("d,B,kind", [(128, 8192, "reg"), (128, 16384, "reg"), (128, 8192 + 37, "vanilla"),
+                                      (40, 4000, "reg"), (128, 64, "reg")])
+def test_workgroup_shapes_agree(d, B, kind, monkeypatch):
+    """Small-batch shape (VPC_TILE=64) vs throughput shape (VPC_TILE=128) on the same inputs: losses and gradients
+    agree up to fp32 summation order, and each is bit-reproducible run to run.  B = 8 192 is one GPU's shard of the
+    headline batch under 8-way strong scaling; 16 384 is the largest batch the library gives the small shape on its own."""
+    params = O.init_params(d, L, seed=3)
+    x, mask, mask_p, eq, ep = synth(B, d, seed=B)
+    res = {}
+    for tile in ("64", "128", "64"):
+        monkeypatch.setenv("VPC_TILE", tile)
+        m = make_model(vpc.Reg_VAE if kind == "reg" else vpc.vanilla_VAE, d, params)
+        tr = vpc.FusedTrainer(m)
+        if kind == "reg":
+            tr.step(x.to(DEV), mask.to(DEV), mask_p.to(DEV), eq.to(DEV), ep.to(DEV), alpha=0.8, beta=0.9, update=False)
+        else:
+            tr.step(x.to(DEV), mask.to(DEV), eps_q=eq.to(DEV), update=False)
+        cur = (tr.loss_value(), tr.grad.clone(), tr.last_blocks)
+        if tile in res:
+            assert res[tile][0] == cur[0] and torch.equal(res[tile][1], cur[1])  # deterministic
+        res[tile] = cur
+    npass = 2 if kind == "reg" else 1
+    assert res["64"][2] == (min((B + 63) // 64, 256) * npass,) * 2
+    assert abs(res["64"][0] - res["128"][0]) <= 2e-6 * abs(res["128"][0])
+    g64, g128 = res["64"][1].cpu().numpy(), res["128"][1].cpu().numpy()
+    assert rel(g64, g128) < 2e-5
+
+
 @pytest.mark.parametrize("d,B", [(128, 300), (100, 130), (125, 70), (128, 40000), (128, 65536)])
 def test_decoder_kernel_variants_agree(d, B, monkeypatch):
     """d in (64, 128] has two fused decoder kernels (8 waves x 1 row tile - the default - and 4 waves x 2 row tiles,
@@ -430,7 +470,8 @@ def test_gradient_reduction_forms_agree():
     x, mask, mask_p, eq, ep = synth(B, d, seed=99)
     tr = vpc.FusedTrainer(make_model(vpc.Reg_VAE, d, params))
     tr.step(x.to(DEV), mask.to(DEV), mask_p.to(DEV), eq.to(DEV), ep.to(DEV), alpha=0.7, beta=0.9, update=False)
-    lay, nb = tr.lay, min(vpc._lib.lib().vpc_num_cus(), (B + 127) // 128)
+    lay, (nbE, nb) = tr.lay, tr.last_blocks
+    assert nbE == nb
     co = tr.coefficients(1, 0.7, 0.9, False)
     args = (lay.n_enc, tr.loss_part, nb, co["cA"][0], co["cE"][0], co["cA"][1], co["bq"], co["bp"], co["cr"], co["wml"],
             B, B, d)

@@ -398,8 +398,14 @@ def test_fused_trainer_at_config3_shape_vs_oracle(nm, kind):
             _close(prm.grad, p[k].grad, 2e-4, f"grad {k}")
     opt.step()
     sd = model.state_dict()
-    for k in p:  # Adam's first step moves every weight by ~lr * sign(g): compare the moved weights
-        _close(sd[k], p[k].detach(), 2e-5, f"param {k}")
+    for k in p:
+        # Adam's first step moves every weight by lr * g / (|g| + eps): an entry whose gradient is pure rounding noise
+        # (|g| ~ 1e-8) may move by up to lr in either direction, so compare the entries with a resolved gradient
+        gref = p[k].grad
+        if gref is None:
+            continue
+        ok = gref.abs() > 1e-3 * gref.abs().max()
+        _close(sd[k].cpu()[ok], p[k].detach()[ok], 2e-5, f"param {k}")
     assert not torch.equal(before, model._flat)
 
 

@@ -35,6 +35,7 @@ _PROTOS = {
     "vpc_layout_sizes": [I, I, I, IP, IP, IP, IP, IP, IP, IP, IP],
     "vpc_build_indices": [I, I, I, P, P, P],
     "vpc_num_cus": [],
+    "vpc_max_partial_blocks": [],
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
     "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P, P, P, P],
@@ -191,6 +192,11 @@ def num_cus() -> int:
     if _NCU is None:
         _NCU = int(lib().vpc_num_cus())
     return _NCU
+
+
+def max_blocks() -> int:
+    """Upper bound of the partial blocks any kernel writes (sizes the partial / loss-partial buffers)."""
+    return int(lib().vpc_max_partial_blocks())
 
 
 # Positions of the hidden units (index H = the constant-1 unit of the bias chain) inside the padded 112- / 64-wide

@@ -21,26 +21,25 @@ namespace vpc {
 // One wave per SIMD (4 waves, up to 512 registers each), every wave owns NB = 2 batch tiles of 16 rows:
 // the whole per-pass live set (activations of both tiles + 92 wgrad accumulators) stays in registers, each
 // weight fragment read from LDS feeds two independent MFMA chains, and barriers involve 4 waves only.
-template <int DT, bool VEC, int MODE>
+// NB = 1: the small-batch shape (64-row workgroup tiles, the passes spread over blockIdx.y; see tile_shape in
+// vpc_abi_internal.h) - same phases, staging and partial-block layout with a single MFMA chain per weight fragment.
+template <int DT, bool VEC, int MODE, int NB>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
     unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    constexpr int CH = DEC_CH, NB = DEC_NB;
+    constexpr int CH = DEC_CH, TILE_ROWS = DEC_WAVES * 16 * NB;  // shadows vpc::TILE_ROWS
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
     constexpr int I6 = (DT + 3) / 4;  // dW6 out tiles per wave (mt = w + 4i)
     const DecImg im(DT);
-    load_image(lds, a.img, im.total);
     const float* W4 = lds + im.oW4;
     const float* W5 = lds + im.oW5;
     const float* W6 = lds + im.oW6;
     float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
     float* red = stB + H1P * CH;   // [DEC_WAVES][8]
-    __syncthreads();
-    VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * w;
     int sb[4];  // per-lane element offsets of the wgrad staging writes (tile 0); tiles add a compile-time constant
@@ -64,6 +63,37 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
             st_tile<false>(base, r, a.L, 4 * q, a.L, rok, v);
         }
     };
+    const int p_lo = a.psplit ? (int)blockIdx.y : 0, p_hi = a.psplit ? p_lo + 1 : a.npass;
+    // Latent statistics of one (tile, pass): this pass's mean / logvar / eps and the other pass's mean / logvar (the KL
+    // coupling).  Optional arrays are aliased to a valid one and and-ed away (no branch: all loads are issued together
+    // instead of one exposed latency per CFG join).  The FIRST (tile, pass) of a workgroup is requested before the weight
+    // image is loaded - in the small-batch shape every workgroup has exactly one, and the two latencies (~2 500 cycles
+    // each, stamps of r02) otherwise add up.
+    struct LatIn { f32x4 mu, lv, e, mo, lo; };
+    auto fetch_lat = [&](int tile, int p, LatIn (&Lt)[NB]) {
+        const bool two = a.npass == 2;
+        const uint32_t has_o = opaque_mask(two), has_e = opaque_mask(a.eps[p] != nullptr);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const long r = (long)tile * TILE_ROWS + w * 16 * NB + nb * 16 + c;
+            const bool rok = r < a.B;
+            Lt[nb].mu = ld_lat(a.mean[p], r, rok);
+            Lt[nb].lv = ld_lat(a.logvar[p], r, rok);
+            Lt[nb].e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], r, rok), has_e);
+            Lt[nb].mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], r, rok), has_o);
+            Lt[nb].lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], r, rok), has_o);
+        }
+    };
+    constexpr bool HOIST = MODE == MODE_FUSED && NB == 1;  // (the two-tile shape has no registers to spare)
+    LatIn Lpre[NB];
+    bool have_pre = false;
+    if (HOIST && (int)blockIdx.x < a.ntiles) {
+        fetch_lat(blockIdx.x, p_lo, Lpre);
+        have_pre = true;
+    }
+    load_image<24>(lds, a.img, im.total);  // 24 576 floats at DT = 8: one round of loads for 256 threads
+    __syncthreads();
+    VPC_STAMP(0);
 
     f32x4 acc6[2][H1T], acc5[2][H2T], acc4 = zero4();
 #pragma unroll
@@ -80,27 +110,34 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
         bool ok[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            row[nb] = (long)tile * TILE_ROWS + w * 32 + nb * 16 + c;
+            row[nb] = (long)tile * TILE_ROWS + w * 16 * NB + nb * 16 + c;
             ok[nb] = row[nb] < a.B;
         }
-        for (int p = 0; p < a.npass; ++p) {
+        for (int p = p_lo; p < p_hi; ++p) {
             asm volatile("" ::: "memory");  // keep LDS weight reads inside the pass (see vpc_enc.hip)
             int cc = c, qq = q;
             launder(cc, qq);
             // ---------------- latent: z = mean + eps * exp(logvar / 2), KL terms and their seeds
             f32x4 z[NB][1], epsfac[NB], dmu_kl[NB], dlv_kl[NB];
+            LatIn Lc[NB];
+            if (MODE == MODE_FUSED) {
+                if (HOIST && have_pre) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) Lc[nb] = Lpre[nb];
+                } else {
+                    fetch_lat(tile, p, Lc);
+                }
+                have_pre = false;
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 epsfac[nb] = zero4(); dmu_kl[nb] = zero4(); dlv_kl[nb] = zero4();
-                if (a.z_in[p]) {
+                if (MODE != MODE_FUSED) {  // API modes: z is given
                     z[nb][0] = ld_lat(a.z_in[p], row[nb], ok[nb]);
                     continue;
                 }
-                const f32x4 mu = ld_lat(a.mean[p], row[nb], ok[nb]);
-                const f32x4 lv = ld_lat(a.logvar[p], row[nb], ok[nb]);
-                // optional arrays are aliased to a valid one and and-ed away (no branch: the loads of this tile can
-                // then be issued together instead of one exposed latency per CFG join)
-                f32x4 e = and4(ld_lat(a.eps[p] ? a.eps[p] : a.mean[p], row[nb], ok[nb]), opaque_mask(a.eps[p] != nullptr));
+                const f32x4 mu = Lc[nb].mu, lv = Lc[nb].lv;
+                f32x4 e = Lc[nb].e;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) e[j] = (4 * q + j < a.L) ? e[j] : 0.f;  // padded eps rows hold noise
 #pragma unroll
@@ -114,9 +151,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     // every KL term and seed below is exactly 0, so no per-lane branch is needed (only the
                     // ml_reg log-likelihood has a non-zero value at 0 and is masked explicitly).
                     const bool two = a.npass == 2;
-                    const uint32_t has_o = opaque_mask(two);
-                    const f32x4 mo = and4(ld_lat(two ? a.mean[1 - p] : a.mean[p], row[nb], ok[nb]), has_o);
-                    const f32x4 lo = and4(ld_lat(two ? a.logvar[1 - p] : a.logvar[p], row[nb], ok[nb]), has_o);
+                    const f32x4 mo = Lc[nb].mo, lo = Lc[nb].lo;
                     const float b0 = (p == 0) ? a.bq : a.bp;
                     const float sgn = (p == 0) ? 1.f : -1.f;  // d KL(q||p) / d mu_q = -d / d mu_p
                     const float crr = two ? a.cr : 0.f;
@@ -176,7 +211,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[NB] = {zero4(), zero4()};
+                    f32x4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
                     tile_fwd_nb<1, S4, NB>(W4, mt, z, acc, cc, qq);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) g1[nb][mt] = relu4(acc[nb]);
@@ -185,7 +222,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[NB] = {zero4(), zero4()};
+                    f32x4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
                     tile_fwd_nb<H2T, 64, NB, NK2>(W5, mt, g1, acc, cc, qq);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) g2[nb][mt] = relu4(acc[nb]);
@@ -196,7 +235,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                 float sa = 0.f, se = 0.f;
                 // Software pipeline over the DT output tiles: while the MFMAs of tile mt+1 run, the VALU work of
                 // tile mt (sigmoid, NLL terms, d/dxhat) is done, and the x / mask loads of tile mt+1 are in flight.
-                f32x4 pre_cur[NB] = {zero4(), zero4()};
+                f32x4 pre_cur[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) pre_cur[nb] = zero4();
                 f32x4 xv_cur[NB];
                 uint32_t ua_cur[NB], ub_cur[NB];
                 const bool hasB = (MODE == MODE_FUSED) && a.mB[p] != nullptr;
@@ -254,7 +295,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 pre_nxt[NB] = {zero4(), zero4()};
+                    f32x4 pre_nxt[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) pre_nxt[nb] = zero4();
                     f32x4 xv_nxt[NB];
                     uint32_t ua_nxt[NB], ub_nxt[NB];
                     if (mt + 1 < DT) {
@@ -352,7 +395,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < H1T; ++mt) {
                         __builtin_amdgcn_sched_barrier(0);
-                        f32x4 acc[NB] = {VPC_DBG(4) ? dpre[0][mt % DT] : zero4(), VPC_DBG(4) ? dpre[1][mt % DT] : zero4()};
+                        f32x4 acc[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_DBG(4) ? dpre[nb][mt % DT] : zero4();
                         if (!VPC_DBG(4)) tile_T_nb<DT, 128, NB>(W6, mt, dpre, acc, cc, qq);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) dg2[nb][mt] = gate_bits(acc[nb], gm2[nb], mt);
@@ -403,7 +448,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < H2T; ++mt) {
                         __builtin_amdgcn_sched_barrier(0);
-                        f32x4 acc[NB] = {VPC_DBG(4) ? dg2[0][mt] : zero4(), VPC_DBG(4) ? dg2[1][mt] : zero4()};
+                        f32x4 acc[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_DBG(4) ? dg2[nb][mt] : zero4();
                         if (!VPC_DBG(4)) tile_T_nb_k<H1T, 64, NB, NK1>(W5, mt, dg2, acc, cc, qq);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) dg1[nb][mt] = gate_bits(acc[nb], gm1[nb], mt);
@@ -446,7 +493,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     }
     VPC_STAMP(9);
     if (MODE == MODE_FWD) return;
-    float* part = a.part + (long)blockIdx.x * DEC_PART + (long)w * DEC_GREGS * 64 + lane;
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = a.part + blk * DEC_PART + (long)w * DEC_GREGS * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -465,14 +513,14 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LOSS_TERMS; ++i) {
-            const float v = wave_sum(s[i]);
+            const float v = wave_sum_dpp(s[i]);  // DPP adds: the shuffle form is 6 dependent ds_bpermute round trips per term
             if (lane == 0) red[w * LOSS_TERMS + i] = v;
         }
         __syncthreads();
         if (threadIdx.x < LOSS_TERMS) {
             double t = 0.0;
             for (int k = 0; k < DEC_WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
-            a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+            a.loss_part[blk * LOSS_TERMS + threadIdx.x] = t;
         }
     }
 #ifdef VPC_ABLATE
@@ -491,21 +539,23 @@ static size_t dec_lds(int DT, int mode) {
 }
 
 template <typename K>
-static int launch(K kern, const DecArgs& args, size_t lds, hipStream_t stream) {
+static int launch(K kern, const DecArgs& args, const TileShape& ts, size_t lds, hipStream_t stream) {
     if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;
-    const int grid = args.ntiles < num_cus() ? args.ntiles : num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC_THREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(ts.grid_x, ts.grid_y), dim3(DEC_THREADS), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
 template <int MODE>
-static int dispatch(const DecArgs& a, bool vec, hipStream_t s) {
+static int dispatch(const DecArgs& a, bool vec, const TileShape& ts, hipStream_t s) {
     const int DT = dt_for(a.d);
     const size_t lds = dec_lds(DT, MODE);
-#define VPC_CASE(T)                                                            \
-    case T:                                                                    \
-        return vec ? launch(dec_kernel<T, true, MODE>, a, lds, s)              \
-                   : launch(dec_kernel<T, false, MODE>, a, lds, s);
+#define VPC_CASE(T)                                                                                   \
+    case T:                                                                                           \
+        if (ts.small)                                                                                 \
+            return vec ? launch(dec_kernel<T, true, MODE, 1>, a, ts, lds, s)                          \
+                       : launch(dec_kernel<T, false, MODE, 1>, a, ts, lds, s);                        \
+        return vec ? launch(dec_kernel<T, true, MODE, DEC_NB>, a, ts, lds, s)                         \
+                   : launch(dec_kernel<T, false, MODE, DEC_NB>, a, ts, lds, s);
     switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
     return VPC_ERR_SHAPE;
@@ -527,9 +577,10 @@ extern "C" int vpc_decoder_fwd(const float* z, const float* dec_img, float* xhat
     if (int e = check_common(B, d, L, 1)) return e;
     DecArgs a{};
     a.img = dec_img; a.z_in[0] = z; a.xhat[0] = xhat; a.B = B; a.d = d; a.L = L; a.npass = 1; a.lp = L;
-    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    const TileShape ts = tile_shape(B, 1);
+    a.ntiles = ts.ntiles; a.psplit = ts.small;
     const bool vec = (d % 4 == 0) && aligned16(xhat);
-    return dispatch<MODE_FWD>(a, vec, (hipStream_t)stream);
+    return dispatch<MODE_FWD>(a, vec, ts, (hipStream_t)stream);
 }
 
 extern "C" int vpc_decoder_bwd(const float* z, const float* dxhat, const float* dec_img, float* dz,
@@ -539,10 +590,11 @@ extern "C" int vpc_decoder_bwd(const float* z, const float* dxhat, const float* 
     DecArgs a{};
     a.img = dec_img; a.z_in[0] = z; a.dxhat[0] = dxhat; a.dz[0] = dz; a.part = partials;
     a.B = B; a.d = d; a.L = L; a.npass = 1; a.lp = L;
-    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
-    if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
+    const TileShape ts = tile_shape(B, 1);
+    a.ntiles = ts.ntiles; a.psplit = ts.small;
+    if (nblocks_out) *nblocks_out = ts.nblocks;
     const bool vec = (d % 4 == 0) && aligned16(dxhat);
-    return dispatch<MODE_BWD>(a, vec, (hipStream_t)stream);
+    return dispatch<MODE_BWD>(a, vec, ts, (hipStream_t)stream);
 }
 
 extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass, const uint8_t* const* maskA,
@@ -561,7 +613,8 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
     if (lat_pitch != 16) return VPC_ERR_ARG;  // the fused kernel works on padded [B][16] latent workspaces only
     a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    const TileShape ts = tile_shape(B, npass);
+    a.ntiles = ts.ntiles; a.psplit = ts.small;
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
 #endif
@@ -574,10 +627,11 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
         vec = vec && ((uintptr_t)a.mA[p] % 4 == 0) && (!a.mB[p] || (uintptr_t)a.mB[p] % 4 == 0);
     }
     if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
-    if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
-    // d in (64, 128]: the 8-wave / one-tile-per-wave kernel (vpc_dec8.hip); VPC_DEC8=0 selects the 4-wave / two-tiles-
-    // per-wave kernel of this file instead (same arguments, same partial-block layout; kept for A/B runs and for d <= 64)
+    if (nblocks_out) *nblocks_out = ts.nblocks;
+    // throughput shape, d in (64, 128]: the 8-wave / one-tile-per-wave kernel (vpc_dec8.hip); VPC_DEC8=0 selects the
+    // 4-wave / two-tiles-per-wave kernel of this file instead (same arguments, same partial-block layout; kept for A/B
+    // runs and for d <= 64).  Small-batch shape: always the 4-wave kernel with one tile per wave.
     const char* e8 = getenv("VPC_DEC8");
-    if (dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, (hipStream_t)stream);
-    return dispatch<MODE_FUSED>(a, vec, (hipStream_t)stream);
+    if (!ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, (hipStream_t)stream);
+    return dispatch<MODE_FUSED>(a, vec, ts, (hipStream_t)stream);
 }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     constexpr int CH = DEC_CH;
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
     const DecImg im(DT);
-    load_image(lds, a.img, im.total);
+    load_image<12>(lds, a.img, im.total);  // one round of loads for 512 threads
     const float* W4 = lds + im.oW4;
     const float* W5 = lds + im.oW5;
     const float* W6 = lds + im.oW6;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LOSS_TERMS; ++i) {
-        const float v = wave_sum(s[i]);
+        const float v = wave_sum_dpp(s[i]);  // DPP adds: the shuffle form is 6 dependent ds_bpermute round trips per term
         if (lane == 0) red[w * LOSS_TERMS + i] = v;
     }
     __syncthreads();
@@ -484,10 +484,9 @@ size_t dec8_lds(int DT) {
 }
 
 // FUSED mode through the 8-wave kernel; returns VPC_ERR_SHAPE when this variant does not cover the shape
-int dec8_dispatch(const DecArgs& a, bool vec, hipStream_t s) {
+int dec8_dispatch(const DecArgs& a, bool vec, int grid, hipStream_t s) {
     const int DT = dt_for(a.d);
     const size_t lds = dec8_lds(DT);
-    const int grid = a.ntiles < num_cus() ? a.ntiles : num_cus();
 #define VPC_CASE8(T)                                                                                         \
     case T: {                                                                                                \
         auto kern = vec ? dec8_kernel<T, true> : dec8_kernel<T, false>;                                      \

@@ -30,6 +30,7 @@ struct DecArgs {
     long B;
     int d, L, npass, ntiles;
     int lp;   // row pitch of the [B][.] latent arrays: L (dense, API tensors) or 16 (padded workspaces)
+    int psplit;  // 1: the passes are spread over blockIdx.y (small-batch shape), 0: every workgroup loops over them
     int dbg;  // ablation mask, only honoured by the diagnostic build (-DVPC_ABLATE); 0 in the product build
 };
 
@@ -68,6 +69,6 @@ __device__ __forceinline__ int opaque_zero() {
 
 
 size_t dec8_lds(int DT);
-int dec8_dispatch(const DecArgs& a, bool vec, hipStream_t s);
+int dec8_dispatch(const DecArgs& a, bool vec, int grid, hipStream_t s);
 
 }  // namespace vpc

@@ -300,11 +300,13 @@ __device__ __forceinline__ f32x4 mask_to_f32(uint32_t u) {
                  (u & 0xff000000u) ? 1.f : 0.f};
 }
 
-// copy a packed image global -> LDS (16-byte granules; n is a multiple of 4).  8 loads are kept in flight per
+// copy a packed image global -> LDS (16-byte granules; n is a multiple of 4).  U loads are kept in flight per
 // thread: a naive load->store loop pays one full memory latency per 16 bytes per thread (tens of us for a
-// 100 KB image, once per workgroup).
+// 100 KB image, once per workgroup).  With U = 8 a 97 KB image takes a 256-thread workgroup three dependent rounds,
+// ~7 500 cycles (stamps, r02): a quarter of the small-batch encoder kernel's life.  The kernels pass U so that the
+// whole image is ONE round of loads (13 per thread at 512 threads, 25 at 256): ~2 500 cycles.
+template <int U = 8>
 __device__ __forceinline__ void load_image(float* lds, const float* img, int n) {
-    constexpr int U = 8;
     const int step = blockDim.x * 4;
     for (int base = threadIdx.x * 4; base < n; base += step * U) {
         f32x4 v[U];

@@ -52,20 +52,24 @@ struct EncFwdArgs {
     float* z[2];
     long B;
     int d, L, npass, ntiles, lp;
+    int psplit;  // 1: the passes are spread over blockIdx.y (small batches), 0: every workgroup loops over them
 };
 
-template <int DT, bool VEC, bool AUG>
-__global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
+// NW = waves per workgroup = 16-row batch tiles per workgroup iteration.  8 (two waves per SIMD, 128-row tiles): the
+// throughput shape.  4 (one wave per SIMD, 64-row tiles, passes spread over blockIdx.y): the small-batch shape - a batch
+// of 8 192 rows then occupies 256 workgroups x 4 waves = every SIMD of the chip with ONE tile-pass each, instead of 64
+// workgroups that each run two passes with two waves per SIMD (the step is latency-bound there, profiles/r01_notes.md).
+template <int DT, bool VEC, bool AUG, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFwdArgs a) {
+    constexpr int TILE_ROWS = 16 * NW;  // shadows vpc::TILE_ROWS (the 8-wave value)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tlast, r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int S1 = s_for_tiles(DT);
     const EncImg im(DT);
-    load_image(lds, a.img, im.total);
-    __syncthreads();
-    VPC_STAMP(0);
     const float* W1 = lds + im.oW1;
     const float* b1 = lds + im.ob1;
     const float* W2 = lds + im.oW2;
@@ -97,15 +101,20 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
             mw[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
                 rm, vo + ((t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0), 0, 0);
     };
+    const int p_lo = a.psplit ? (int)blockIdx.y : 0, p_hi = a.psplit ? p_lo + 1 : a.npass;
+    // the first tile's x / mask words are requested BEFORE the weight image: both latencies overlap
     if (PIPE && (int)blockIdx.x < a.ntiles) {
         fetch_x((long)blockIdx.x * TILE_ROWS);
-        fetch_m(a.mask[0], (long)blockIdx.x * TILE_ROWS);
+        fetch_m(a.mask[p_lo], (long)blockIdx.x * TILE_ROWS);
     }
+    load_image<(NW == 8 ? 13 : 25)>(lds, a.img, im.total);
+    __syncthreads();
+    VPC_STAMP(0);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const long row = (long)tile * TILE_ROWS + w * 16 + c;
         const bool ok = row < a.B;
-        for (int p = 0; p < a.npass; ++p) {
+        for (int p = p_lo; p < p_hi; ++p) {
             // the weight image never changes after the prologue: without this compiler barrier LICM hoists
             // every LDS weight read out of the pass loop and spills ~1 KB/lane of it to scratch
             asm volatile("" ::: "memory");
@@ -122,12 +131,12 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
                     const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
                     xin[t] = xraw[t] * mask_to_f32(mw[t] & vm);  // x.float() * mask  (VAE.py:388)
                 }
-                if (p + 1 < a.npass) {
+                if (p + 1 < p_hi) {
                     fetch_m(a.mask[p + 1], row0);
                 } else if (tile + (int)gridDim.x < a.ntiles) {
                     const long tn = row0 + (long)gridDim.x * TILE_ROWS;
                     fetch_x(tn);
-                    fetch_m(a.mask[0], tn);
+                    fetch_m(a.mask[p_lo], tn);
                 }
             } else {
 #pragma unroll
@@ -174,8 +183,10 @@ __global__ __launch_bounds__(THREADS, 2) void enc_fwd_kernel(EncFwdArgs a) {
     }
 #ifdef VPC_ABLATE
     if ((blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2)
-        printf("enc_fwd blk %d wave %d cycles: prologue %llu loadx %llu L1 %llu L2 %llu L3+st %llu\n", blockIdx.x,
-               (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4]);
+        printf("enc_fwd blk %d wave %d cycles: prologue %llu loadx %llu L1 %llu L2 %llu L3+st %llu | total %llu cycles in %llu x 10 ns\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4],
+               (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin),
+               (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_begin));
 #endif
 }
 
@@ -190,6 +201,7 @@ struct EncBwdArgs {
     float* part;
     long B;
     int d, L, npass, ntiles, lp, dbg;
+    int psplit;  // as EncFwdArgs
 };
 
 #ifdef VPC_ABLATE
@@ -198,52 +210,95 @@ struct EncBwdArgs {
 #define ABLE(bit) false
 #endif
 
-template <int DT, bool VEC, bool AUG>
-__global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
+// NW as in enc_fwd_kernel.  Every wave owns OWN = 8 / NW slices of each wgrad (the 8-wave kernel: one): in tiles
+// w + NW i of dW1 / dW2 and tiles w + NW i of dW3, written to the partial block in the slots of the 8-wave layout
+// (vpc_layout.h), so the gradient reduction does not care which shape ran.
+template <int DT, bool VEC, bool AUG, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    // Staging is full width (all 128 batch rows of the workgroup tile at once): ONE write + barrier + read round per
+    // Staging is full width (all batch rows of the workgroup tile at once): ONE write + barrier + read round per
     // wgrad round (two rounds: layer 2, then layers 1 + 3 together), 4 barriers per pass instead of 12 (barriers were 16 %
     // of this kernel, `profiles/r01_notes.md`).  That
     // fits in LDS because the B operand of the layer-1 wgrad - x * mask, the only use of x in this kernel - never
     // goes through LDS: a B fragment wants batch rows along the register index and features along the lanes, which
     // is how row-major x lies in memory, so the tile's owner wave reads it from global memory directly.
-    constexpr int CH = TILE_ROWS;
+    constexpr int TILE_ROWS = 16 * NW, CH = TILE_ROWS, NTHR = 64 * NW, OWN = 8 / NW;
     constexpr bool PIPE = VEC && !AUG;
     const EncImg im(DT);
     const int nW = im.total - im.oW2;  // only W2, W3 are needed (layer 1 has no dgrad)
-    load_image(lds, a.img + im.oW2, nW);
     float* W2 = lds;
     float* W3 = lds + (im.oW3 - im.oW2);
     float* stA = lds + nW;             // [112][CH]  dY operands (dml, dh2, dh1)
     float* stB = stA + H1P * CH;       // [112][CH]  activations (h2, h1)
-    float* db1s = stB + H1P * CH;      // [WAVES][128]: per-wave bias-gradient sums (no atomics across waves: bit-reproducible)
-    for (int i = threadIdx.x; i < WAVES * 128; i += THREADS) db1s[i] = 0.f;
-    __syncthreads();
+    float* db1s = stB + H1P * CH;      // [NW][128]: per-wave bias-gradient sums (no atomics across waves: bit-reproducible)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int p_lo = a.psplit ? (int)blockIdx.y : 0, p_hi = a.psplit ? p_lo + 1 : a.npass;
+    // row-layout operands of one (tile, pass) through range-checked buffer descriptors: rows past B read 0 - zero seeds make
+    // dh2, dh1 and every wgrad contribution of such a row exactly zero.  (hipcc turns `ok ? load : 0` into an exec-masked
+    // branch with a vmcnt(0) wait at the join.)  The first (tile, pass) of the workgroup is requested before the weight
+    // image: in the small-batch shape there is only one, and the two latencies otherwise add up.
+    struct RowIn { f32x4 dml[2], h2[H2T], h1[H1T]; };
+    auto fetch_rows = [&](int tile, int p, RowIn& R) {
+        const long row0 = (long)tile * TILE_ROWS;
+        const int lrow = w * 16 + c;
+        if (a.lp == 16) {
+            R.dml[0] = ld_rows(rows_rsrc(a.dmean[p], row0, a.B, 16), lrow, 16, 4 * q);
+            R.dml[1] = ld_rows(rows_rsrc(a.dlogvar[p], row0, a.B, 16), lrow, 16, 4 * q);
+        } else {
+            const long row = row0 + lrow;
+            R.dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, row < a.B);
+            R.dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, row < a.B);
+        }
+        const __amdgpu_buffer_rsrc_t rh2 = rows_rsrc(a.h2[p], row0, a.B, H2P), rh1 = rows_rsrc(a.h1[p], row0, a.B, H1P);
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) R.h2[t] = ld_rows(rh2, lrow, H2P, 16 * t + 4 * q);
+#pragma unroll
+        for (int t = 0; t < H1T; ++t) R.h1[t] = ld_rows(rh1, lrow, H1P, 16 * t + 4 * q);
+    };
+    // (small-batch shape only: the 8-wave kernel sits at its 256-register limit and would spill the extra copy)
+    constexpr bool HOIST = NW == 4;
+    RowIn Rpre;
+    bool have_pre = false;
+    if (HOIST && (int)blockIdx.x < a.ntiles) {
+        fetch_rows(blockIdx.x, p_lo, Rpre);
+        have_pre = true;
+    }
+    load_image<(NW == 8 ? 5 : 10)>(lds, a.img + im.oW2, nW);
+    for (int i = threadIdx.x; i < NW * 128; i += NTHR) db1s[i] = 0.f;
+    __syncthreads();
     int sb[4];  // per-lane element offsets of the staging writes (tile 0); tiles add a compile-time constant
     stage_bases<CH>(sb, 16 * w, c, q);
 
-    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4(), dbacc[H1T];
+    f32x4 acc1[OWN][H1T], acc2[OWN][H2T], acc3[OWN], dbacc[H1T];
 #pragma unroll
-    for (int i = 0; i < H1T; ++i) acc1[i] = dbacc[i] = zero4();
+    for (int i = 0; i < H1T; ++i) dbacc[i] = zero4();
 #pragma unroll
-    for (int i = 0; i < H2T; ++i) acc2[i] = zero4();
+    for (int o = 0; o < OWN; ++o) {
+        acc3[o] = zero4();
+#pragma unroll
+        for (int i = 0; i < H1T; ++i) acc1[o][i] = zero4();
+#pragma unroll
+        for (int i = 0; i < H2T; ++i) acc2[o][i] = zero4();
+    }
 
-    // layer-1 input feature of this lane as a B-fragment column (owner: wave w < DT -> input tile w)
-    const int fB = 16 * w + c;
+    // layer-1 input features of this lane as B-fragment columns (owned in tiles w + NW o)
     const int din = AUG ? 2 * a.d : a.d;
-    const bool fx = fB < a.d, fm = AUG && fB >= a.d && fB < din;        // x * mask column / appended mask column
-    const int colB = fx ? fB : (fm ? fB - a.d : 0);
+    bool fx[OWN], fm[OWN];
+    int colB[OWN];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int fB = 16 * (w + NW * o) + c;
+        fx[o] = fB < a.d; fm[o] = AUG && fB >= a.d && fB < din;  // x * mask column / appended mask column
+        colB[o] = fx[o] ? fB : (fm[o] ? fB - a.d : 0);
+    }
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * TILE_ROWS;
-        const long row = row0 + w * 16 + c;
-        const bool ok = row < a.B;
-        for (int p = 0; p < a.npass; ++p) {
+        for (int p = p_lo; p < p_hi; ++p) {
             int cc = c, qq = q;
             launder(cc, qq);
             VPC_STAMP(0);
@@ -257,42 +312,29 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             const long mrem = (a.B - row0) * (long)a.d;
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t*>(a.mask[p]) + row0 * a.d, 0, mrem > 0xffffffffL ? 0xffffffffu : (uint32_t)mrem, 0x00020000);
-            const int vo0 = 4 * qq * a.d + colB;  // element offset of (row 4 q, this lane's column)
-            auto ld_xb = [&](int sl, f32x4& xv, uint32_t& mb) {
+            auto ld_xb = [&](int o, int sl, f32x4& xv, uint32_t& mb) {
+                const int vo0 = 4 * qq * a.d + colB[o];  // element offset of (row 4 q, this lane's column)
                 mb = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int o = vo0 + (16 * sl + j) * a.d;
-                    xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4 * o, 0, 0));
-                    mb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rm, o, 0, 0) << (8 * j);
+                    const int off = vo0 + (16 * sl + j) * a.d;
+                    xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4 * off, 0, 0));
+                    mb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rm, off, 0, 0) << (8 * j);
                 }
             };
-            auto mk_fb = [&](const f32x4& xv, uint32_t mb) -> f32x4 {
+            auto mk_fb = [&](int o, const f32x4& xv, uint32_t mb) -> f32x4 {
                 const f32x4 m = mask_to_f32(mb);
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fx ? xv[j] * m[j] : (fm ? m[j] : 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = fx[o] ? xv[j] * m[j] : (fm[o] ? m[j] : 0.f);
                 return v;
             };
-            // row-layout operands through range-checked buffer descriptors: rows past B read 0 - zero seeds make dh2, dh1
-            // and every wgrad contribution of such a row exactly zero.  (hipcc turns `ok ? load : 0` into an exec-masked
-            // branch with a vmcnt(0) wait at the join.)
-            const int lrow = w * 16 + c;
-            f32x4 dml[2], h2[H2T], h1[H1T];
-            if (a.lp == 16) {
-                dml[0] = ld_rows(rows_rsrc(a.dmean[p], row0, a.B, 16), lrow, 16, 4 * q);
-                dml[1] = ld_rows(rows_rsrc(a.dlogvar[p], row0, a.B, 16), lrow, 16, 4 * q);
-            } else {
-                dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, ok);
-                dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, ok);
-            }
-            {
-                const __amdgpu_buffer_rsrc_t rh2 = rows_rsrc(a.h2[p], row0, a.B, H2P), rh1 = rows_rsrc(a.h1[p], row0, a.B, H1P);
-#pragma unroll
-                for (int t = 0; t < H2T; ++t) h2[t] = ld_rows(rh2, lrow, H2P, 16 * t + 4 * q);
-#pragma unroll
-                for (int t = 0; t < H1T; ++t) h1[t] = ld_rows(rh1, lrow, H1P, 16 * t + 4 * q);
-            }
+            RowIn R;
+            if (HOIST && have_pre) R = Rpre; else fetch_rows(tile, p, R);
+            have_pre = false;
+            f32x4 (&dml)[2] = R.dml;
+            f32x4 (&h2)[H2T] = R.h2;
+            f32x4 (&h1)[H1T] = R.h1;
             // (dW3~ += dml * h2^T is staged and computed together with the layer-1 wgrad below: the B staging buffer is
             // free in that round because x never goes through LDS - 4 instead of 6 barriers per pass)
             VPC_STAMP(1);
@@ -302,7 +344,7 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
             VPC_STAMP(2);
-            // ---- dW2~ += dh2 * h1^T   (owner: wave w<7 -> in tile w, all 4 out tiles)
+            // ---- dW2~ += dh2 * h1^T   (owner: wave w -> in tiles w + NW o < 7, all 4 out tiles)
             launder(cc, qq);
             if (!ABLE(2)) __syncthreads();
             if (!ABLE(1)) {
@@ -312,33 +354,38 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, h1[t], sb);
             }
             if (!ABLE(2)) __syncthreads();
-            if (w < H1T && !ABLE(4)) {
 #pragma unroll
-                for (int s = 0; s < CH / 16; ++s) {
-                    asm volatile("" ::: "memory");
-                    const f32x4 fb = stage_frag<CH>(stB, w, s, cc, qq);
-                    // A fragments double-buffered by hand (hipcc sinks each LDS read to its first use: one exposed
-                    // LDS latency per 4 MFMAs); the sched_barrier pins the read of mt+1 above the MFMAs of mt
-                    f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
+            for (int o = 0; o < OWN; ++o) {
+                if (w + NW * o < H1T && !ABLE(4)) {
 #pragma unroll
-                    for (int mt = 0; mt < H2T; ++mt) {
-                        const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H2T ? mt + 1 : mt, s, cc, qq);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int s = 0; s < CH / 16; ++s) {
+                        asm volatile("" ::: "memory");
+                        const f32x4 fb = stage_frag<CH>(stB, w + NW * o, s, cc, qq);
+                        // A fragments double-buffered by hand (hipcc sinks each LDS read to its first use: one exposed
+                        // LDS latency per 4 MFMAs); the sched_barrier pins the read of mt+1 above the MFMAs of mt
+                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc2[mt] = VPC_MFMA(fa[j], fb[j], acc2[mt]);
-                        fa = fn;
+                        for (int mt = 0; mt < H2T; ++mt) {
+                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H2T ? mt + 1 : mt, s, cc, qq);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc2[o][mt] = VPC_MFMA(fa[j], fb[j], acc2[o][mt]);
+                            fa = fn;
+                        }
                     }
                 }
             }
             VPC_STAMP(3);
             // the first two B slices of the layer-1 wgrad come in under the dh1 MFMAs
             constexpr int NS = CH / 16;
-            f32x4 xb[3];  // rotating: slices s, s + 1, s + 2
-            uint32_t mbb[3];
-            if (w < DT) {
-                ld_xb(0, xb[0], mbb[0]);
-                ld_xb(1, xb[1], mbb[1]);
-            }
+            f32x4 xb[OWN][3];  // rotating: slices s, s + 1, s + 2
+            uint32_t mbb[OWN][3];
+#pragma unroll
+            for (int o = 0; o < OWN; ++o)
+                if (w + NW * o < DT) {
+                    ld_xb(o, 0, xb[o][0], mbb[o][0]);
+                    ld_xb(o, 1, xb[o][1], mbb[o][1]);
+                }
             // ---- dh1 = relu'(h1) * (W2~^T dh2);  db1 += dh1
             launder(cc, qq);
             f32x4 dh1[H1T];
@@ -351,13 +398,13 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
                 dbacc[mt] += dh1[mt];
             }
             VPC_STAMP(4);
-            // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w<DT -> in tile w, all 7 out tiles; B straight from global)
+            // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w -> in tiles w + NW o < DT, all 7 out tiles; B straight from global)
             launder(cc, qq);
             if (!ABLE(2)) __syncthreads();
             if (!ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
-                // operands of dW3~ (owner: wave w -> out tile w>>2, in tile w&3): h2 -> stB tiles 0..3, dml -> stB tiles 4, 5
+                // operands of dW3~ (tile t8 = w + NW o -> out tile t8 >> 2, in tile t8 & 3): h2 -> stB tiles 0..3, dml -> stB tiles 4, 5
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, h2[t], sb);
                 stage_write_b<CH>(stB, H2T, dml[0], sb);
@@ -365,26 +412,33 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             }
             if (!ABLE(2)) __syncthreads();
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const f32x4 fa = stage_frag<CH>(stB, H2T + (w >> 2), s, cc, qq);
-                const f32x4 fb = stage_frag<CH>(stB, w & 3, s, cc, qq);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc3 = VPC_MFMA(fa[j], fb[j], acc3);
-            }
-            if (w < DT && !ABLE(4)) {
+            for (int o = 0; o < OWN; ++o) {
+                const int t8 = w + NW * o;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    asm volatile("" ::: "memory");  // keep each slice's loads in its slice (hipcc hoists all 8 otherwise)
-                    if (s + 2 < NS) ld_xb(s + 2, xb[(s + 2) % 3], mbb[(s + 2) % 3]);
-                    const f32x4 fb = mk_fb(xb[s % 3], mbb[s % 3]);
-                    f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
+                    const f32x4 fa = stage_frag<CH>(stB, H2T + (t8 >> 2), s, cc, qq);
+                    const f32x4 fb = stage_frag<CH>(stB, t8 & 3, s, cc, qq);
 #pragma unroll
-                    for (int mt = 0; mt < H1T; ++mt) {
-                        const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H1T ? mt + 1 : mt, s, cc, qq);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < 4; ++j) acc3[o] = VPC_MFMA(fa[j], fb[j], acc3[o]);
+                }
+            }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc1[mt] = VPC_MFMA(fa[j], fb[j], acc1[mt]);
-                        fa = fn;
+            for (int o = 0; o < OWN; ++o) {
+                if (w + NW * o < DT && !ABLE(4)) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        asm volatile("" ::: "memory");  // keep each slice's loads in its slice (hipcc hoists all 8 otherwise)
+                        if (s + 2 < NS) ld_xb(o, s + 2, xb[o][(s + 2) % 3], mbb[o][(s + 2) % 3]);
+                        const f32x4 fb = mk_fb(o, xb[o][s % 3], mbb[o][s % 3]);
+                        f32x4 fa = stage_frag<CH>(stA, 0, s, cc, qq);
+#pragma unroll
+                        for (int mt = 0; mt < H1T; ++mt) {
+                            const f32x4 fn = stage_frag<CH>(stA, mt + 1 < H1T ? mt + 1 : mt, s, cc, qq);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc1[o][mt] = VPC_MFMA(fa[j], fb[j], acc1[o][mt]);
+                            fa = fn;
+                        }
                     }
                 }
             }
@@ -404,24 +458,28 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
             v += dpp_mov<0x140>(v);  // row_mirror: every lane of the 16-lane row holds the row sum
             if (c == 0) db1s[w * 128 + 16 * mt + 4 * q + j] = v;
         }
-    // ---- write this workgroup's gradient partial block
-    float* part = a.part + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+    // ---- write this workgroup's gradient partial block (8-wave slot layout: owned slice o is "wave" w + NW o)
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
-    for (int mt = 0; mt < H1T; ++mt)
+    for (int o = 0; o < OWN; ++o) {
+        float* part = a.part + blk * ENC_PART + (long)(w + NW * o) * GREGS * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = acc1[mt][j];
+        for (int mt = 0; mt < H1T; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < H2T; ++mt)
+            for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = acc1[o][mt][j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = acc2[mt][j];
+        for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
+            for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = acc2[o][mt][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[o][j];
+    }
     __syncthreads();  // every wave's db1s row is complete
     if (threadIdx.x < 128) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < WAVES; ++k) t += db1s[k * 128 + threadIdx.x];
-        a.part[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = t;
+        for (int k = 0; k < NW; ++k) t += db1s[k * 128 + threadIdx.x];
+        a.part[blk * ENC_PART + WAVES * GREGS * 64 + threadIdx.x] = t;
     }
 #ifdef VPC_ABLATE
     VPC_STAMP(6);
@@ -432,16 +490,15 @@ __global__ __launch_bounds__(THREADS, 2) void enc_bwd_kernel(EncBwdArgs a) {
 }
 
 static size_t enc_fwd_lds(int DT) { return sizeof(float) * EncImg(DT).total; }
-static size_t enc_bwd_lds(int DT) {
+static size_t enc_bwd_lds(int DT, int nw) {
     const EncImg im(DT);
-    return sizeof(float) * ((im.total - im.oW2) + 2 * H1P * TILE_ROWS + WAVES * 128);
+    return sizeof(float) * ((im.total - im.oW2) + 2 * H1P * 16 * nw + nw * 128);
 }
 
 template <typename K, typename A>
-static int launch(K kern, const A& args, int ntiles, size_t lds, hipStream_t stream) {
+static int launch(K kern, const A& args, int grid_x, int grid_y, int nw, size_t lds, hipStream_t stream) {
     if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;
-    const int grid = ntiles < num_cus() ? ntiles : num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid_x, grid_y), dim3(64 * nw), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -460,7 +517,8 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
     if (lat_pitch != L && z) return VPC_ERR_ARG;  // z is only produced in the dense [B][L] layout
     EncFwdArgs a{};
     a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    const TileShape ts = tile_shape(B, npass);
+    a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
         if (!mask[p] || !h1[p] || !h2[p] || !mean[p] || !logvar[p]) return VPC_ERR_ARG;
@@ -472,13 +530,15 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
     const int DT = dt_for(mask_augm ? 2 * d : d);
     const size_t lds = enc_fwd_lds(DT);
     hipStream_t s = (hipStream_t)stream;
-#define VPC_CASE(T)                                                                               \
-    case T:                                                                                       \
-        return mask_augm ? launch(enc_fwd_kernel<T, false, true>, a, a.ntiles, lds, s)            \
-               : vec     ? launch(enc_fwd_kernel<T, true, false>, a, a.ntiles, lds, s)            \
-                         : launch(enc_fwd_kernel<T, false, false>, a, a.ntiles, lds, s);
+#define VPC_LAUNCH(T, NW)                                                                                   \
+    (mask_augm ? launch(enc_fwd_kernel<T, false, true, NW>, a, ts.grid_x, ts.grid_y, NW, lds, s)            \
+     : vec     ? launch(enc_fwd_kernel<T, true, false, NW>, a, ts.grid_x, ts.grid_y, NW, lds, s)            \
+               : launch(enc_fwd_kernel<T, false, false, NW>, a, ts.grid_x, ts.grid_y, NW, lds, s))
+#define VPC_CASE(T) \
+    case T: return ts.small ? VPC_LAUNCH(T, 4) : VPC_LAUNCH(T, 8);
     switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
+#undef VPC_LAUNCH
     return VPC_ERR_SHAPE;
 }
 
@@ -495,7 +555,8 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG_ENC")) a.dbg = atoi(e);
 #endif
-    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    const TileShape ts = tile_shape(B, npass);
+    a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
         if (!mask[p] || !h1[p] || !h2[p] || !dmean[p] || !dlogvar[p]) return VPC_ERR_ARG;
@@ -503,16 +564,17 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
         vec = vec && ((uintptr_t)mask[p] % 4 == 0);
         if (!aligned16(h1[p]) || !aligned16(h2[p])) return VPC_ERR_ARG;
     }
-    if (nblocks_out) *nblocks_out = a.ntiles < num_cus() ? a.ntiles : num_cus();
+    if (nblocks_out) *nblocks_out = ts.nblocks;
     const int DT = dt_for(mask_augm ? 2 * d : d);
-    const size_t lds = enc_bwd_lds(DT);
     hipStream_t s = (hipStream_t)stream;
-#define VPC_CASE(T)                                                                               \
-    case T:                                                                                       \
-        return mask_augm ? launch(enc_bwd_kernel<T, false, true>, a, a.ntiles, lds, s)            \
-               : vec     ? launch(enc_bwd_kernel<T, true, false>, a, a.ntiles, lds, s)            \
-                         : launch(enc_bwd_kernel<T, false, false>, a, a.ntiles, lds, s);
+#define VPC_LAUNCH(T, NW)                                                                                                  \
+    (mask_augm ? launch(enc_bwd_kernel<T, false, true, NW>, a, ts.grid_x, ts.grid_y, NW, enc_bwd_lds(T, NW), s)            \
+     : vec     ? launch(enc_bwd_kernel<T, true, false, NW>, a, ts.grid_x, ts.grid_y, NW, enc_bwd_lds(T, NW), s)            \
+               : launch(enc_bwd_kernel<T, false, false, NW>, a, ts.grid_x, ts.grid_y, NW, enc_bwd_lds(T, NW), s))
+#define VPC_CASE(T) \
+    case T: return ts.small ? VPC_LAUNCH(T, 4) : VPC_LAUNCH(T, 8);
     switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
+#undef VPC_LAUNCH
     return VPC_ERR_SHAPE;
 }

@@ -5,6 +5,7 @@
 #include "vpc_device.h"
 #include "vpc_abi_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <map>
@@ -27,6 +28,30 @@ int num_cus() {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     if (dev >= 0 && dev < MAXDEV) cache[dev].store(v, std::memory_order_relaxed);
     return v;
+}
+
+TileShape tile_shape(long B, int npass) {
+    const int ncu = num_cus();
+    const long t64 = (B + 63) / 64, t128 = (B + 127) / 128;
+    bool small = t64 * npass <= 2L * ncu;
+    if (const char* e = getenv("VPC_TILE")) {
+        const int v = atoi(e);
+        if (v == 64) small = true;
+        if (v == 128) small = false;
+    }
+    TileShape t;
+    t.small = small ? 1 : 0;
+    if (small) {
+        t.ntiles = (int)t64;
+        t.grid_x = (int)(t64 < ncu ? t64 : ncu);
+        t.grid_y = npass;
+    } else {
+        t.ntiles = (int)t128;
+        t.grid_x = (int)(t128 < ncu ? t128 : ncu);
+        t.grid_y = 1;
+    }
+    t.nblocks = t.grid_x * t.grid_y;
+    return t;
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device function attribute: remembered per (device, kernel)
@@ -604,6 +629,7 @@ extern "C" int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int
 }
 
 extern "C" int vpc_num_cus(void) { return num_cus(); }
+extern "C" int vpc_max_partial_blocks(void) { return 2 * num_cus(); }
 
 // ================================================================================================
 extern "C" int vpc_pack_weights(const float* flat_params, const int* pack_idx, float* img, int n, void* stream) {

@@ -245,7 +245,7 @@ class EDDITrainer:
         self.exp_avg = torch.zeros(n, device=self.dev)
         self.exp_avg_sq = torch.zeros(n, device=self.dev)
         self.accum = torch.zeros(1, device=self.dev)
-        ncu = L.num_cus()
+        ncu = L.max_blocks()  # partial blocks any kernel may write
         self.partD = torch.empty(ncu * self.lay.dec_part, device=self.dev)
         self.loss_part = torch.empty(ncu, 8, dtype=torch.float64, device=self.dev)
         self.pidx, self.gidx = self.lay.device_tables(self.dev)

@@ -55,7 +55,7 @@ class FusedTrainer:
         self.exp_avg = torch.zeros(n, device=self.dev)
         self.exp_avg_sq = torch.zeros(n, device=self.dev)
         self.accum = torch.zeros(1, device=self.dev)
-        ncu = L.num_cus()
+        ncu = L.max_blocks()  # partial blocks any kernel may write (2 x CUs: small-batch shape)
         self.partE = torch.empty(ncu * self.lay.enc_part, device=self.dev)
         self.partD = torch.empty(ncu * self.lay.dec_part, device=self.dev)
         self.loss_part = torch.empty(ncu, 8, dtype=torch.float64, device=self.dev)
@@ -188,6 +188,7 @@ class FusedTrainer:
                           self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm)
         # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
+        self.last_blocks = (nbE, nbD)
         if update and self.world_size == 1 and _state is None:
             self.step_count += 1
             ops.reduce_step_adam(self.partE, nbE, lay.enc_part, self.partD, nbD,

@@ -143,7 +143,7 @@ class _VAEBase(nn.Module):
         key = (which, str(device))
         if key not in self._part:
             n = lay.enc_part if which == "enc" else lay.dec_part
-            self._part[key] = torch.empty(L.num_cus() * n, device=device)
+            self._part[key] = torch.empty(L.max_blocks() * n, device=device)
         return self._part[key]
 
     def _split_flat(self, flat, lo, hi):
