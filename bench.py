@@ -37,6 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: bf16 MFMA = 16 x the fp32 MFMA rate (~2.5 PF dense)
+# MFMA peak the algorithmic FLOPs are priced against: a bf16x3 product issues three bf16 MFMAs per fp32 product
+PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0, "bf16": BF16_MFMA_PEAK_TFLOPS}
+HBM_PEAK_TBS = 8.0
 
 
 def flops_per_sample(d, L, passes=2):
@@ -110,6 +114,8 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32",
+                    help="f32 = the headline (exact fp32 MFMA); bf16x3 / bf16 = extra lines on v_mfma_f32_16x16x32_bf16")
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the loop rotates over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the settle steps after the W warm-up steps")
@@ -142,7 +148,7 @@ def main():
     xs = [torch.rand(B, d, generator=g).to(dev) for _ in range(args.batches)]
     masks = [(torch.rand(B, d, generator=g) < 0.7).to(dev) for _ in range(args.batches)]
     # one shared seed: Philox counters are keyed by the global row, so ranks draw disjoint parts of one stream
-    tr = vpc.FusedTrainer(model, lr=1e-3, seed=0, world_size=world, rank=rank)
+    tr = vpc.FusedTrainer(model, lr=1e-3, seed=0, world_size=world, rank=rank, precision=args.precision)
     kw = dict(alpha=1.0, beta=1.0, p_missingness=30, epoch=1, global_batch=Bg, row_lo=lo)
     it = [0]
 
@@ -235,15 +241,17 @@ def main():
     out = {
         "metric": "training samples/sec (ELBO+consistency step), B=65536 d=128",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {"workload": f"Reg_VAE kl_reg alpha=1 beta=1 training step, synthetic tabular {rows}, "
                                f"d={d}, L={Ld}, MCAR mask 0.7, p_missingness=30, Adam lr=1e-3, "
                                f"{args.batches} resident batches rotated",
                    "global_batch": Bg, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "vpc::dec8_kernel<8,true> (vpc_decoder_fused)",
-                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(B, d, Ld),
+                     "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                     "frac": achieved / PEAK[args.precision],
+                     "traffic": measured_traffic(B, d, Ld) if args.precision == "f32" else None,
                      "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},
         "kernels_ms": kern_ms,
         "step_tflops_algorithmic": fl["total"] * B * world / (ms_step * 1e-3) / 1e12,

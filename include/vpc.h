@@ -52,6 +52,21 @@ int vpc_num_cus(void);
  * separate workgroups): size `partials` / `loss_partials` buffers for this many blocks. */
 int vpc_max_partial_blocks(void);
 
+/* ---- precision of the matrix products (argument `precision` of vpc_encoder_fwd / vpc_encoder_bwd /
+ * vpc_decoder_fused) ------------------------------------------------------------------------------------------
+ *   0  f32     v_mfma_f32_16x16x4_f32 on the fp32 images (exact fp32 FMA chains; the path every parity claim of the
+ *              1e-4 target refers to)
+ *   1  bf16x3  "split bf16": operands carried as bf16 hi + bf16 lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16
+ *              with fp32 accumulation - fp32-class accuracy at 16/3 of the fp32 MFMA rate
+ *   2  bf16    plain bf16 inputs, fp32 accumulation (BASELINE configs 2 / 3 name bf16); loss math stays fp32
+ * 1 and 2 take the images of vpc_build_indices_bf16 / vpc_pack_weights_bf16 instead of the fp32 images, exist for
+ * d % 4 == 0 in the plain (not mask-augmented) encoder, and in vpc_decoder_fused for d in (64, 128]. */
+int vpc_layout_sizes_bf16(int d, int L, int mask_augm, int* enc_img_floats, int* dec_img_floats);
+/* HOST arrays: pack_idx_bf[n_params], img_template_bf[enc + dec floats of vpc_layout_sizes_bf16] */
+int vpc_build_indices_bf16(int d, int L, int mask_augm, int* pack_idx_bf, float* img_template_bf);
+/* img_bf <- flat parameters as bf16 hi / lo pairs (the layer-1 bias stays fp32) */
+int vpc_pack_weights_bf16(const float* flat_params, const int* pack_idx_bf, float* img_bf, int n, void* stream);
+
 /* ---- parameters --------------------------------------------------------------------------------- */
 
 /* img[pack_idx[i]] = flat_params[i].  Replaces nothing in the reference (nn.Linear keeps [out][in]). */
@@ -79,16 +94,16 @@ int vpc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * 16-byte aligned workspaces of the fused path, pad entries written as 0; z must then be NULL). */
 int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                    float* const* logvar, float* const* z, int lat_pitch, int mask_augm, long B, int d, int L,
-                    void* stream);
+                    float* const* logvar, float* const* z, int lat_pitch, int mask_augm, int precision, long B, int d,
+                    int L, void* stream);
 
 /* Autograd of the above (src/experiment_main/train.py:115): given d loss / d mean and d loss / d logvar
  * (with the reparameterisation path already folded in) accumulate the encoder weight gradients of all
  * passes into partial blocks [*nblocks_out][enc_part_floats].  x needs no gradient (layer-0 dgrad skipped). */
 int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                     const float* const* h1, const float* const* h2, const float* const* dmean,
-                    const float* const* dlogvar, int lat_pitch, int mask_augm, float* partials, int* nblocks_out,
-                    long B, int d, int L, void* stream);
+                    const float* const* dlogvar, int lat_pitch, int mask_augm, int precision, float* partials,
+                    int* nblocks_out, long B, int d, int L, void* stream);
 
 /* ---- decoder: Reg_VAE.decoder, src/models/VAE.py:397-401 ----------------------------------------- */
 
@@ -126,7 +141,7 @@ int vpc_decoder_fused(const float* x, const float* dec_img, int npass, const uin
                       const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* mean,
                       const float* const* logvar, const float* const* eps, const float* eps_ml, float bq, float bp,
                       float cr, float wml, float inv_B, float x_logvar, float* const* dmean,
-                      float* const* dlogvar, int lat_pitch, float* partials, double* loss_partials,
+                      float* const* dlogvar, int lat_pitch, int precision, float* partials, double* loss_partials,
                       int* nblocks_out, long B, int d, int L, void* stream);
 
 /* out9[0] = loss / B_global with the NLL constants of the B_local rows this rank processed (so that the

@@ -73,7 +73,7 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert l.vpc_layout_sizes(65, 10, 1, *[None] * 8) == 2 and l.vpc_layout_sizes(64, 10, 1, *[None] * 8) == 0
     assert l.vpc_layout_sizes(14, 16, 0, *[None] * 8) == 2
     assert l.vpc_layout_sizes(14, 10, 0, *[None] * 8) == 0
-    assert l.vpc_encoder_fwd(None, None, 1, None, None, None, None, None, None, None, 10, 0, 4, 14, 10, None) == 1
+    assert l.vpc_encoder_fwd(None, None, 1, None, None, None, None, None, None, None, 10, 0, 0, 4, 14, 10, None) == 1
     assert l.vpc_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None, None, None, None, None, None) == 1
     assert l.vpc_build_inverse_maps(None, 1, 2, 4, 4, None, None) == 1
     assert l.vpc_draw_mask(None, None, 8, 0.5, 0, 0, 0, None) == 1

@@ -39,14 +39,17 @@ _PROTOS = {
     "vpc_pack_weights": [P, P, P, I, P],
     "vpc_reduce_partials": [P, I, L_, P, P, I, F, P],
     "vpc_adam_step": [P, P, P, P, I, F, F, F, F, L_, P, P, P, P, P, P],
-    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, L_, I, I, P],
-    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, P, IP, L_, I, I, P],
+    "vpc_layout_sizes_bf16": [I, I, I, IP, IP],
+    "vpc_build_indices_bf16": [I, I, I, P, P],
+    "vpc_pack_weights_bf16": [P, P, P, I, P],
+    "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, I, L_, I, I, P],
+    "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
     "vpc_decoder_bwd": [P, P, P, P, P, IP, L_, I, I, P],
     "vpc_loss_fwd_bwd": [P, I, PP, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, P, F, F, F, F, F, F, PP, PP, PP, P, I,
                          IP, L_, I, I, P],
-    "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, P,
-                          P, IP, L_, I, I, P],
+    "vpc_decoder_fused": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, PP, PP, P, F, F, F, F, F, F, PP, PP, I, I,
+                          P, P, IP, L_, I, I, P],
     "vpc_loss_finalize": [P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P],
     "vpc_build_inverse_maps": [P, I, I, L_, L_, P, P],
     "vpc_reduce_step": [P, I, L_, P, I, L_, P, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, C.c_longlong,
@@ -160,6 +163,21 @@ class Layout:
         key = str(device)
         if key not in self._dev:
             self._dev[key] = (torch.from_numpy(self.pack_idx).to(device), torch.from_numpy(self.grad_idx).to(device))
+        return self._dev[key]
+
+    def bf16_tables(self, device):
+        """(pack_idx_bf [n_params] int32 on `device`, img_template_bf numpy [enc + dec floats], enc_img floats) of the
+        bf16 weight images (precision 1 / 2: csrc/vpc_bf16.h)."""
+        key = ("bf16", str(device))
+        if key not in self._dev:
+            l = lib()
+            e, dd = C.c_int(), C.c_int()
+            check(l.vpc_layout_sizes_bf16(self.d, self.L, self.mask_augm, C.byref(e), C.byref(dd)), "vpc_layout_sizes_bf16")
+            idx = np.empty(self.n_params, np.int32)
+            tmpl = np.empty(e.value + dd.value, np.float32)
+            check(l.vpc_build_indices_bf16(self.d, self.L, self.mask_augm, idx.ctypes.data_as(P), tmpl.ctypes.data_as(P)),
+                  "vpc_build_indices_bf16")
+            self._dev[key] = (torch.from_numpy(idx).to(device), tmpl, e.value)
         return self._dev[key]
 
     def inverse_maps(self, device):

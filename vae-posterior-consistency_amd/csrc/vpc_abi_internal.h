@@ -23,7 +23,7 @@ int num_cus();  // CUs of the current device (cached)
 //                     gives every SIMD one tile-pass instead of giving a quarter of the CUs four.
 // VPC_TILE=64 / 128 in the environment forces a shape (A/B runs, tests).  nblocks <= 2 * num_cus() always.
 struct TileShape { int small, ntiles, grid_x, grid_y, nblocks; };
-TileShape tile_shape(long B, int npass);
+TileShape tile_shape(long B, int npass, bool force_big = false);  // force_big: kernels that exist in the throughput shape only
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size); false on a HIP error
 bool lds_attr_done(const void* kern, size_t lds);
 }  // namespace vpc

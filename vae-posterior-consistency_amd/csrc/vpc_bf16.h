@@ -1,0 +1,158 @@
+// bf16-input MFMA engine for the register-chained MLP kernels (gfx950: v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Two precisions behind one code path (PREC template parameter of the kernels):
+//   PREC_BF16X3  "split bf16": every fp32 operand v is carried as hi = bf16(v), lo = bf16(v - hi) and a product is
+//                hi*hi + hi*lo + lo*hi (three MFMAs into one fp32 accumulator; the dropped lo*lo term is ~2^-18
+//                relative).  ~fp32 accuracy (the 1e-4 loss tolerance holds, tests/test_bf16.py) at 16/3 of the fp32 MFMA rate.
+//   PREC_BF16    plain bf16 inputs (one MFMA per product, 16 x the fp32 MFMA rate), fp32 accumulation, fp32 loss math.
+//
+// How the register chaining survives the wider K.  One 16x16x32 MFMA contracts 32 input features.  Its B operand wants
+// lane (c = l & 15, q = l >> 4) to hold the 8 features of k-slots (q, j), j = 0..7.  A wave holds an activation tile in
+// the MFMA C/D layout: lane (c, q) has features 16 t + 4 q + r (r = 0..3) of tile t for batch row c.  Two adjacent tiles
+// (2 kb, 2 kb + 1) therefore ARE one B operand if k-slot (q, j) is taken to mean
+//        feature(kb, q, j) = 32 kb + 16 (j >> 2) + 4 q + (j & 3)
+// - no lane movement, only four v_cvt_pk_bf16_f32 per operand - and the weight image is simply stored with its columns
+// in that order (host-side index table, vpc_build_indices_bf16).
+//
+// bf16 weight image of one layer: `rows` rows of KP dwords (KP = inputs padded to 32).  The 32-byte "pair slot"
+// pi = 4 kb + q of a row holds [hi: 8 x bf16 | lo: 8 x bf16] for k-slots (kb, q, 0..7); pi is XOR-swizzled with
+// row & min(15, KP / 8 - 1).  The image has the row pitch (in dwords) and size of the fp32 image with S = KP.
+//   forward  A fragment (row 16 mt + m, block kb, lane group q): ds_read_b128 (hi) + ds_read_b128 (lo)
+//   dgrad    A fragment of W^T (in feature 16 mt + m, block kb of OUT features, lane group q): the same image read with
+//            ds_read_b64_tr_b16 (hardware transpose of a 4-row x 16-column block of 16-bit elements): 2 reads for hi, 2 for lo
+//   wgrad    contracts over batch rows: both operands come from the fp32 staging buffers of the fp32 kernels, two 16-row
+//            slices per 32-row k-block, converted to bf16 in registers (same permutation on both sides, so any order works)
+#pragma once
+#include "vpc_device.h"
+
+namespace vpc {
+
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define VPC_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- host + device: geometry of the bf16 image of a layer with `k_in` inputs
+VPC_HD constexpr int bf_kp(int k_in) { return (k_in + 31) / 32 * 32; }          // row pitch in dwords
+VPC_HD constexpr int bf_mask(int kp) { return (kp / 8 - 1) < 15 ? (kp / 8 - 1) : 15; }
+// u16 index of the hi element of (row, input feature f) inside a layer image with pitch kp dwords; lo is 8 u16 later
+VPC_HD inline int bf_elem(int row, int f, int kp) {
+    const int kb = f >> 5, h = (f >> 4) & 1, q = (f >> 2) & 3, i = f & 3;
+    const int pi = (4 * kb + q) ^ (row & bf_mask(kp));
+    return row * kp * 2 + pi * 16 + 4 * h + i;
+}
+
+#if defined(__HIPCC__)
+// ---- fp32 -> bf16 pairs (round to nearest even: v_cvt_pk_bf16_f32) and the split residual
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t pk_bf16_lo(float a, float b, uint32_t hi) {
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    return pk_bf16(a - ah, b - bh);
+}
+struct BfOp {  // one MFMA operand (8 k-slots per lane): hi part and, for the split form, the residual
+    bf16x8 hi, lo;
+};
+template <int PREC>
+__device__ __forceinline__ BfOp bf_pack(f32x4 t0, f32x4 t1) {
+    u32x4 h = {pk_bf16(t0[0], t0[1]), pk_bf16(t0[2], t0[3]), pk_bf16(t1[0], t1[1]), pk_bf16(t1[2], t1[3])};
+    BfOp o;
+    o.hi = __builtin_bit_cast(bf16x8, h);
+    if (PREC == PREC_BF16X3) {
+        u32x4 l = {pk_bf16_lo(t0[0], t0[1], h[0]), pk_bf16_lo(t0[2], t0[3], h[1]), pk_bf16_lo(t1[0], t1[1], h[2]),
+                   pk_bf16_lo(t1[2], t1[3], h[3])};
+        o.lo = __builtin_bit_cast(bf16x8, l);
+    } else {
+        o.lo = o.hi;
+    }
+    return o;
+}
+// acc += A * B in the chosen precision
+template <int PREC>
+__device__ __forceinline__ f32x4 bf_mma(const BfOp& a, const BfOp& b, f32x4 acc) {
+    if (PREC == PREC_BF16X3) {
+        acc = VPC_MFMA_BF(a.lo, b.hi, acc);
+        acc = VPC_MFMA_BF(a.hi, b.lo, acc);
+    }
+    return VPC_MFMA_BF(a.hi, b.hi, acc);
+}
+
+// activations of a layer as MFMA B operands: KT fp32 tiles -> (KT + 1) / 2 blocks of 32 features
+template <int PREC, int KT>
+__device__ __forceinline__ void bf_acts(const f32x4 (&in)[KT], BfOp (&out)[(KT + 1) / 2]) {
+#pragma unroll
+    for (int kb = 0; kb < (KT + 1) / 2; ++kb)
+        out[kb] = bf_pack<PREC>(in[2 * kb], 2 * kb + 1 < KT ? in[2 * kb + 1] : zero4());
+}
+
+// ---- forward A fragment of weight rows 16 mt + m, block kb
+template <int PREC, int KP>
+__device__ __forceinline__ BfOp bf_wfrag(const float* W, int mt, int kb, int m, int q) {
+    constexpr int MASK = bf_mask(KP);
+    const float* p = W + (16 * mt + m) * KP + 8 * ((4 * kb + q) ^ (m & MASK));
+    BfOp o;
+    o.hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p));
+    if (PREC == PREC_BF16X3) o.lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p + 4));
+    else o.lo = o.hi;
+    return o;
+}
+// out tile mt of  W[out][in] * in  (in: KB blocks; NKB of them hold data)
+template <int PREC, int KB, int KP, int NKB = KB>
+__device__ __forceinline__ f32x4 bf_tile_fwd(const float* W, int mt, const BfOp (&in)[KB], f32x4 acc, int m, int q) {
+    BfOp a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) a[kb] = bf_wfrag<PREC, KP>(W, mt, kb, m, q);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) acc = bf_mma<PREC>(a[kb], in[kb], acc);
+    return acc;
+}
+
+// ---- transposed A fragment: in-feature tile mt (lane m = in feature 16 mt + m), block kb of the layer's OUT features.
+// ds_read_b64_tr_b16: lane 4 rr + pp of 16-lane group g supplies the address of block row rr, columns 4 pp .. 4 pp + 3;
+// lane i of the group receives column i of the 4 rows (row rr in element rr).  Group g = q reads rows 32 kb + 4 q + rr
+// (k-slots j = rr) and, second read, 16 rows further (j = 4 + rr); its 16 columns are the in features of tile mt, which
+// sit in pair slot 4 (mt >> 1) + pp at element offset 4 (mt & 1) of each row.
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+__device__ __forceinline__ s16x4 ds_tr16(const float* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(const_cast<float*>(p)));
+}
+template <int PREC, int KP>
+__device__ __forceinline__ BfOp bf_wfrag_T(const float* W, int mt, int kb, int lane) {
+    constexpr int MASK = bf_mask(KP);
+    const int q = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 32 * kb + 4 * q + rr, r1 = r0 + 16;
+    const int pi = 4 * (mt >> 1) + pp, e = 2 * (mt & 1);  // element offset 4 (mt & 1) u16 = 2 (mt & 1) dwords
+    const float* p0 = W + r0 * KP + 8 * (pi ^ (r0 & MASK)) + e;
+    const float* p1 = W + r1 * KP + 8 * (pi ^ (r1 & MASK)) + e;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    BfOp o;
+    const s16x4 h0 = ds_tr16(p0), h1 = ds_tr16(p1);
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    o.hi = __builtin_bit_cast(bf16x8, h);
+    if (PREC == PREC_BF16X3) {
+        const s16x4 l0 = ds_tr16(p0 + 4), l1 = ds_tr16(p1 + 4);
+        const s16x8 l = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        o.lo = __builtin_bit_cast(bf16x8, l);
+    } else {
+        o.lo = o.hi;
+    }
+    return o;
+}
+// out tile mt of  W^T[in][out] * in  where `in` has KB blocks over W's ROW (out-feature) index
+template <int PREC, int KB, int KP, int NKB = KB>
+__device__ __forceinline__ f32x4 bf_tile_T(const float* W, int mt, const BfOp (&in)[KB], f32x4 acc, int lane) {
+    BfOp a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) a[kb] = bf_wfrag_T<PREC, KP>(W, mt, kb, lane);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) acc = bf_mma<PREC>(a[kb], in[kb], acc);
+    return acc;
+}
+#endif  // __HIPCC__
+
+}  // namespace vpc

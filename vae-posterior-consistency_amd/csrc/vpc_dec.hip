@@ -602,18 +602,20 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
                                  const float* const* mean, const float* const* logvar, const float* const* eps,
                                  const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B,
                                  float x_logvar, float* const* dmean, float* const* dlogvar, int lat_pitch,
-                                 float* partials, double* loss_partials, int* nblocks_out, long B, int d, int L,
-                                 void* stream) {
+                                 int precision, float* partials, double* loss_partials, int* nblocks_out, long B, int d,
+                                 int L, void* stream) {
     if (!x || !dec_img || !maskA || !cA || !cE || !mean || !logvar || !dmean || !dlogvar || !partials ||
         !loss_partials)
         return VPC_ERR_ARG;
     if (int e = check_common(B, d, L, npass)) return e;
+    if (precision < 0 || precision > 2) return VPC_ERR_ARG;
+    if (precision != 0 && dt_for(d) != 8) return VPC_ERR_SHAPE;  // bf16 variants: the 8-wave kernel, d in (64, 128]
     DecArgs a{};
     a.x = x; a.img = dec_img; a.part = partials; a.loss_part = loss_partials; a.eps_ml = eps_ml;
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
     if (lat_pitch != 16) return VPC_ERR_ARG;  // the fused kernel works on padded [B][16] latent workspaces only
     a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    const TileShape ts = tile_shape(B, npass);
+    const TileShape ts = tile_shape(B, npass, precision != 0);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
@@ -632,6 +634,7 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     // 4-wave / two-tiles-per-wave kernel of this file instead (same arguments, same partial-block layout; kept for A/B
     // runs and for d <= 64).  Small-batch shape: always the 4-wave kernel with one tile per wave.
     const char* e8 = getenv("VPC_DEC8");
-    if (!ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, (hipStream_t)stream);
+    if (precision != 0) return dec8_dispatch(a, vec, ts.grid_x, precision, (hipStream_t)stream);
+    if (!ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, 0, (hipStream_t)stream);
     return dispatch<MODE_FUSED>(a, vec, ts, (hipStream_t)stream);
 }

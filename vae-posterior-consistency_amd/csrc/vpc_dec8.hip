@@ -12,6 +12,7 @@
 // registers 28 (mt >> 2) + ...), so the host-side index tables and the reduction do not change.
 #include "vpc_abi_internal.h"
 #include "vpc_device.h"
+#include "vpc_bf16.h"
 #include "vpc_dec_args.h"
 
 namespace vpc {
@@ -72,7 +73,8 @@ __device__ __forceinline__ f32x4 tile_T_p2(const float* W, int mt, const f32x4 (
     return acc;
 }
 
-template <int DT, bool VEC>
+// PREC != PREC_F32: the bf16 engine of vpc_bf16.h on the bf16 decoder image (DecImgBf: W4 rows are 32 dwords).
+template <int DT, bool VEC, int PREC = PREC_F32>
 __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -81,14 +83,18 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #endif
     constexpr int CH = DEC_CH;
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
-    const DecImg im(DT);
-    load_image<12>(lds, a.img, im.total);  // one round of loads for 512 threads
+    constexpr bool BF = PREC != PREC_F32;
+    constexpr int S4K = BF ? 32 : S4;  // row pitch of the W4 image
+    const DecImg im(DT, S4K);
+    load_image<13>(lds, a.img, im.total);  // one round of loads for 512 threads
     const float* W4 = lds + im.oW4;
     const float* W5 = lds + im.oW5;
     const float* W6 = lds + im.oW6;
     float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
-    float* red = stB + H1P * CH;   // [8][LOSS_TERMS]
+    // [8][LOSS_TERMS] for the end-of-kernel loss reduction; with the (4 KB larger) bf16 image the kernel is at the 160 KB
+    // LDS limit, so there it aliases the staging buffer (only used after the last staging round)
+    float* red = BF ? stA : stB + H1P * CH;
     __syncthreads();
     VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
@@ -160,19 +166,30 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     if (4 * q + j == a.L) z[0][0][j] = 1.f;  // constant feature that drives the bias chain
                 // ---------------- decoder forward
                 f32x4 g1[1][H2T], g2[1][H1T];
+                BfOp zb[1];
+                if (BF) zb[0] = bf_pack<PREC>(z[0][0], zero4());
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
-                    f32x4 acc[1] = {zero4()};
-                    tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
-                    g1[0][mt] = relu4(acc[0]);
+                    if (BF) {
+                        g1[0][mt] = relu4(bf_tile_fwd<PREC, 1, S4K>(W4, mt, zb, zero4(), cc, qq));
+                    } else {
+                        f32x4 acc[1] = {zero4()};
+                        tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
+                        g1[0][mt] = relu4(acc[0]);
+                    }
                 }
                 VPC_CUT();
                 launder(cc, qq);
+                BfOp g1b[2];
+                if (BF) bf_acts<PREC, H2T>(g1[0], g1b);
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
-                    g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
+                    if (BF) g2[0][mt] = relu4(bf_tile_fwd<PREC, 2, 64>(W5, mt, g1b, zero4(), cc, qq));
+                    else g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
                 }
+                BfOp g2b[4];
+                if (BF) bf_acts<PREC, H1T>(g2[0], g2b);
                 launder(cc, qq);
                 VPC_STAMP(2);
                 VPC_CUT();
@@ -217,7 +234,8 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     uint32_t ua = ua_n, ub = ub_n;
                     if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
                     f32x4 pre[1];
-                    pre[0] = tile_fwd_p2<H1T, 128, NK1>(W6, mt, g2[0], cc, qq);
+                    if (BF) pre[0] = bf_tile_fwd<PREC, 4, 128>(W6, mt, g2b, zero4(), cc, qq);
+                    else pre[0] = tile_fwd_p2<H1T, 128, NK1>(W6, mt, g2[0], cc, qq);
                     if (VEC && mt >= DT / 2) {
                         const uint32_t vm = opaque_mask(16 * mt + 4 * q + 3 < a.d);
                         ua &= vm;
@@ -260,7 +278,22 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[0][t], sb);
                     }
                     if (!ABL(2)) __syncthreads();
-                    if (own6 && !ABL(4)) {
+                    if (BF) {
+                        if (own6) {
+#pragma unroll
+                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                                for (int nt = 0; nt < H1T; ++nt) {
+                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
+                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+                                    acc6[nt] = bf_mma<PREC>(fa, fb, acc6[nt]);
+                                }
+                            }
+                        }
+                    } else if (own6 && !ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -282,25 +315,32 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg2[1][H1T];
+                BfOp dpreb[(DT + 1) / 2];
+                if (BF) bf_acts<PREC, DT>(dpre[0], dpreb);
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     VPC_CUT();
-                    dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
+                    if (BF) dg2[0][mt] = gate_bits(bf_tile_T<PREC, (DT + 1) / 2, 128>(W6, mt, dpreb, zero4(), 16 * qq + cc), gm2, mt);
+                    else dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
                 }
                 // ---------------- dW5~ += dg2 * g1^T   (28 tiles; owners below)
                 VPC_STAMP(5);
                 VPC_CUT();
                 launder(cc, qq);
                 // g1 is RECOMPUTED here (16 MFMAs from z) instead of being kept live since the forward pass: 16 registers
-                f32x4 g1b[1][H2T];
+                f32x4 g1r[1][H2T];
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
-                    f32x4 acc[1] = {zero4()};
-                    tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
-                    g1b[0][mt] = relu4(acc[0]);
+                    if (BF) {
+                        g1r[0][mt] = relu4(bf_tile_fwd<PREC, 1, S4K>(W4, mt, zb, zero4(), cc, qq));
+                    } else {
+                        f32x4 acc[1] = {zero4()};
+                        tile_fwd_nb<1, S4, 1>(W4, mt, z, acc, cc, qq);
+                        g1r[0][mt] = relu4(acc[0]);
+                    }
                 }
-                const uint32_t gm1 = relu_bits<H2T>(g1b[0]);
+                const uint32_t gm1 = relu_bits<H2T>(g1r[0]);
                 const int nt5 = w & 3, mt5 = 4 * (w >> 2);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -309,12 +349,27 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[0][t], sb);
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1b[0][t], sb);
+                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1r[0][t], sb);
                     }
                     if (!ABL(2)) __syncthreads();
                     // owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3; out tile 7 does not exist, so waves 4..7
                     // run three: 7 tiles on every SIMD (waves s and s + 4) instead of 8 / 8 / 8 / 4 with one wave per out tile
-                    if (!ABL(4)) {
+                    if (BF) {
+#pragma unroll
+                        for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt5, 2 * sb2, cc, qq),
+                                                          stage_frag<CH>(stB, nt5, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (i < 3 || w < 4) {
+                                    const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt5 + i, 2 * sb2, cc, qq),
+                                                                  stage_frag<CH>(stA, mt5 + i, 2 * sb2 + 1, cc, qq));
+                                    acc5[i] = bf_mma<PREC>(fa, fb, acc5[i]);
+                                }
+                            }
+                        }
+                    } else if (!ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -340,11 +395,16 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg1[1][H2T];
+                BfOp dg2b[4];
+                if (BF) bf_acts<PREC, H1T>(dg2[0], dg2b);
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     VPC_CUT();
-                    dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
+                    // (W5 has 112 rows: the fourth 32-row block reads 16 rows of the W6 image behind it, finite bf16 values
+                    // that meet the exact zeros of dg2's padding tile)
+                    if (BF) dg1[0][mt] = gate_bits(bf_tile_T<PREC, 4, 64>(W5, mt, dg2b, zero4(), 16 * qq + cc), gm1, mt);
+                    else dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
                 VPC_STAMP(7);
@@ -360,7 +420,18 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         stage_write_b<CH>(stB, 0, z[0][0], sb);
                     }
                     if (!ABL(2)) __syncthreads();
-                    if (own4 && !ABL(4)) {
+                    if (BF) {
+                        if (own4) {
+#pragma unroll
+                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
+                                const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, 0, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stB, 0, 2 * sb2 + 1, cc, qq));
+                                acc4 = bf_mma<PREC>(fa, fb, acc4);
+                            }
+                        }
+                    } else if (own4 && !ABL(4)) {
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
@@ -371,7 +442,13 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                 }
                 launder(cc, qq);
-                tile_T_nb_k<H2T, S4, 1, NK2>(W4, 0, dg1, dzt, cc, qq);
+                if (BF) {
+                    BfOp dg1b[2];
+                    bf_acts<PREC, H2T>(dg1[0], dg1b);
+                    dzt[0] = bf_tile_T<PREC, 2, S4K>(W4, 0, dg1b, zero4(), 16 * qq + cc);
+                } else {
+                    tile_T_nb_k<H2T, S4, 1, NK2>(W4, 0, dg1, dzt, cc, qq);
+                }
             }
             VPC_STAMP(8);
             // ---------------- KL terms, their seeds, and the total seeds on the encoder outputs (KL part + reparameterisation)
@@ -477,19 +554,23 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #endif
 }
 
-size_t dec8_lds(int DT) {
-    const DecImg im(DT);
+size_t dec8_lds(int DT, int prec) {
+    const DecImg im(DT, prec == PREC_F32 ? S4 : 32);
     const int na = 16 * DT > H1P ? 16 * DT : H1P;
-    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + DEC8_WAVES * LOSS_TERMS);
+    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + (prec == PREC_F32 ? DEC8_WAVES * LOSS_TERMS : 0));
 }
 
 // FUSED mode through the 8-wave kernel; returns VPC_ERR_SHAPE when this variant does not cover the shape
-int dec8_dispatch(const DecArgs& a, bool vec, int grid, hipStream_t s) {
+int dec8_dispatch(const DecArgs& a, bool vec, int grid, int prec, hipStream_t s) {
     const int DT = dt_for(a.d);
-    const size_t lds = dec8_lds(DT);
+    const size_t lds = dec8_lds(DT, prec);
+    if (prec != PREC_F32 && !vec) return VPC_ERR_SHAPE;  // the bf16 variants cover the vector layout (d % 4 == 0) only
 #define VPC_CASE8(T)                                                                                         \
     case T: {                                                                                                \
-        auto kern = vec ? dec8_kernel<T, true> : dec8_kernel<T, false>;                                      \
+        auto kern = prec == PREC_BF16X3 ? dec8_kernel<T, true, PREC_BF16X3>                                   \
+                    : prec == PREC_BF16 ? dec8_kernel<T, true, PREC_BF16>                                     \
+                    : vec               ? dec8_kernel<T, true, PREC_F32>                                      \
+                                        : dec8_kernel<T, false, PREC_F32>;                                    \
         if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;                    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC8_THREADS), lds, s, a);                                 \
         return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;                                       \

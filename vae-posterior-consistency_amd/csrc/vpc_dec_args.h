@@ -68,7 +68,7 @@ __device__ __forceinline__ int opaque_zero() {
 
 
 
-size_t dec8_lds(int DT);
-int dec8_dispatch(const DecArgs& a, bool vec, int grid, hipStream_t s);
+size_t dec8_lds(int DT, int prec);
+int dec8_dispatch(const DecArgs& a, bool vec, int grid, int prec, hipStream_t s);
 
 }  // namespace vpc

@@ -4,6 +4,7 @@
 //   h = relu(W1 (x*mask) + b1); h = relu(W2 h + b2); mean, logvar = chunk(W3 h + b3); z = mean + eps*exp(logvar/2)
 // and its autograd (src/experiment_main/train.py:115).  See vpc_device.h for the register-chained design.
 #include "vpc_device.h"
+#include "vpc_bf16.h"
 #include "vpc_abi_internal.h"
 
 namespace vpc {
@@ -59,7 +60,9 @@ struct EncFwdArgs {
 // throughput shape.  4 (one wave per SIMD, 64-row tiles, passes spread over blockIdx.y): the small-batch shape - a batch
 // of 8 192 rows then occupies 256 workgroups x 4 waves = every SIMD of the chip with ONE tile-pass each, instead of 64
 // workgroups that each run two passes with two waves per SIMD (the step is latency-bound there, profiles/r01_notes.md).
-template <int DT, bool VEC, bool AUG, int NW>
+// PREC (vpc_bf16.h): PREC_F32 = v_mfma_f32_16x16x4_f32 on the fp32 image; PREC_BF16X3 / PREC_BF16 = v_mfma_f32_16x16x32_bf16
+// on the bf16 image (same geometry: same row pitches, b1 stays fp32), activations converted tile pair by tile pair.
+template <int DT, bool VEC, bool AUG, int NW, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFwdArgs a) {
     constexpr int TILE_ROWS = 16 * NW;  // shadows vpc::TILE_ROWS (the 8-wave value)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,25 +146,51 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFw
                 for (int t = 0; t < DT; ++t) xin[t] = ld_input<VEC, AUG>(a.x, a.mask[p], row, a.d, t, q, ok);
             }
             VPC_STAMP(1);
-            f32x4 h1[H1T];
+            f32x4 h1[H1T], h2[H2T], mu, lv;
+            if (PREC == PREC_F32) {
 #pragma unroll
-            for (int mt = 0; mt < H1T; ++mt) {
-                f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
-                acc = tile_fwd<DT, S1>(W1, mt, xin, acc, cc, qq);
-                h1[mt] = relu4(acc);
-                st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
-            }
-            VPC_STAMP(2);
-            launder(cc, qq);
-            f32x4 h2[H2T];
+                for (int mt = 0; mt < H1T; ++mt) {
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
+                    acc = tile_fwd<DT, S1>(W1, mt, xin, acc, cc, qq);
+                    h1[mt] = relu4(acc);
+                    st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
+                }
+                VPC_STAMP(2);
+                launder(cc, qq);
 #pragma unroll
-            for (int mt = 0; mt < H2T; ++mt) {
-                h2[mt] = relu4(tile_fwd<H1T, 128, NK1>(W2, mt, h1, zero4(), cc, qq));
-                st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
+                for (int mt = 0; mt < H2T; ++mt) {
+                    h2[mt] = relu4(tile_fwd<H1T, 128, NK1>(W2, mt, h1, zero4(), cc, qq));
+                    st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
+                }
+                VPC_STAMP(3);
+                mu = tile_fwd<H2T, 64, NK2>(W3, 0, h2, zero4(), cc, qq);
+                lv = tile_fwd<H2T, 64, NK2>(W3, 1, h2, zero4(), cc, qq);
+            } else {
+                constexpr int KB1 = (DT + 1) / 2;
+                BfOp xb[KB1];
+                bf_acts<PREC, DT>(xin, xb);
+#pragma unroll
+                for (int mt = 0; mt < H1T; ++mt) {
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
+                    acc = bf_tile_fwd<PREC, KB1, S1>(W1, mt, xb, acc, cc, qq);
+                    h1[mt] = relu4(acc);
+                    st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
+                }
+                VPC_STAMP(2);
+                launder(cc, qq);
+                BfOp h1b[4];
+                bf_acts<PREC, H1T>(h1, h1b);
+#pragma unroll
+                for (int mt = 0; mt < H2T; ++mt) {
+                    h2[mt] = relu4(bf_tile_fwd<PREC, 4, 128>(W2, mt, h1b, zero4(), cc, qq));
+                    st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
+                }
+                VPC_STAMP(3);
+                BfOp h2b[2];
+                bf_acts<PREC, H2T>(h2, h2b);
+                mu = bf_tile_fwd<PREC, 2, 64>(W3, 0, h2b, zero4(), cc, qq);
+                lv = bf_tile_fwd<PREC, 2, 64>(W3, 1, h2b, zero4(), cc, qq);
             }
-            VPC_STAMP(3);
-            const f32x4 mu = tile_fwd<H2T, 64, NK2>(W3, 0, h2, zero4(), cc, qq);
-            const f32x4 lv = tile_fwd<H2T, 64, NK2>(W3, 1, h2, zero4(), cc, qq);
             if (a.lp == 16) {  // padded workspaces: rows are 16 floats, features >= L are exact zeros
                 st_rows(rows_rsrc(a.mean[p], row0, a.B, 16), lrow, 16, 4 * q, mu);
                 st_rows(rows_rsrc(a.logvar[p], row0, a.B, 16), lrow, 16, 4 * q, lv);
@@ -213,7 +242,7 @@ struct EncBwdArgs {
 // NW as in enc_fwd_kernel.  Every wave owns OWN = 8 / NW slices of each wgrad (the 8-wave kernel: one): in tiles
 // w + NW i of dW1 / dW2 and tiles w + NW i of dW3, written to the partial block in the slots of the 8-wave layout
 // (vpc_layout.h), so the gradient reduction does not care which shape ran.
-template <int DT, bool VEC, bool AUG, int NW>
+template <int DT, bool VEC, bool AUG, int NW, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -342,7 +371,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             launder(cc, qq);
             f32x4 dh2[H2T];
 #pragma unroll
-            for (int mt = 0; mt < H2T; ++mt) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
+            for (int mt = 0; mt < H2T; ++mt) {
+                if (PREC == PREC_F32) {
+                    dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
+                } else {
+                    BfOp dmlb[1] = {bf_pack<PREC>(dml[0], dml[1])};
+                    dh2[mt] = gate4(bf_tile_T<PREC, 1, 64>(W3, mt, dmlb, zero4(), 16 * qq + cc), h2[mt]);
+                }
+            }
             VPC_STAMP(2);
             // ---- dW2~ += dh2 * h1^T   (owner: wave w -> in tiles w + NW o < 7, all 4 out tiles)
             launder(cc, qq);
@@ -356,7 +392,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             if (!ABLE(2)) __syncthreads();
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
-                if (w + NW * o < H1T && !ABLE(4)) {
+                if (PREC != PREC_F32) {
+                    if (w + NW * o < H1T) {
+#pragma unroll
+                        for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                            asm volatile("" ::: "memory");
+                            const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, w + NW * o, 2 * sb2, cc, qq),
+                                                          stage_frag<CH>(stB, w + NW * o, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                            for (int mt = 0; mt < H2T; ++mt) {
+                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stA, mt, 2 * sb2 + 1, cc, qq));
+                                acc2[o][mt] = bf_mma<PREC>(fa, fb, acc2[o][mt]);
+                            }
+                        }
+                    }
+                } else if (w + NW * o < H1T && !ABLE(4)) {
 #pragma unroll
                     for (int s = 0; s < CH / 16; ++s) {
                         asm volatile("" ::: "memory");
@@ -385,13 +436,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                 if (w + NW * o < DT) {
                     ld_xb(o, 0, xb[o][0], mbb[o][0]);
                     ld_xb(o, 1, xb[o][1], mbb[o][1]);
+                    if (PREC != PREC_F32) ld_xb(o, 2, xb[o][2], mbb[o][2]);  // bf16: slices are consumed in pairs
                 }
             // ---- dh1 = relu'(h1) * (W2~^T dh2);  db1 += dh1
             launder(cc, qq);
             f32x4 dh1[H1T];
 #pragma unroll
             for (int mt = 0; mt < H1T; ++mt) {
-                dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
+                if (PREC == PREC_F32) {
+                    dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
+                } else {
+                    BfOp dh2b[2];
+                    bf_acts<PREC, H2T>(dh2, dh2b);
+                    dh1[mt] = gate4(bf_tile_T<PREC, 2, 128>(W2, mt, dh2b, zero4(), 16 * qq + cc), h1[mt]);
+                }
                 // db1: per-lane running sums over all tile-passes; the cross-lane reduction happens ONCE, after the
                 // loops (it used to be 4 DPP adds + a predicated ds_add per value and pass: ~170 VALU and 28 exec-masked
                 // basic blocks in the middle of the dgrad MFMA stream)
@@ -414,17 +472,49 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
                 const int t8 = w + NW * o;
+                if (PREC == PREC_F32) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const f32x4 fa = stage_frag<CH>(stB, H2T + (t8 >> 2), s, cc, qq);
-                    const f32x4 fb = stage_frag<CH>(stB, t8 & 3, s, cc, qq);
+                    for (int s = 0; s < NS; ++s) {
+                        const f32x4 fa = stage_frag<CH>(stB, H2T + (t8 >> 2), s, cc, qq);
+                        const f32x4 fb = stage_frag<CH>(stB, t8 & 3, s, cc, qq);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc3[o] = VPC_MFMA(fa[j], fb[j], acc3[o]);
+                        for (int j = 0; j < 4; ++j) acc3[o] = VPC_MFMA(fa[j], fb[j], acc3[o]);
+                    }
+                } else {
+#pragma unroll
+                    for (int sb2 = 0; sb2 < NS / 2; ++sb2) {
+                        const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stB, H2T + (t8 >> 2), 2 * sb2, cc, qq),
+                                                      stage_frag<CH>(stB, H2T + (t8 >> 2), 2 * sb2 + 1, cc, qq));
+                        const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, t8 & 3, 2 * sb2, cc, qq),
+                                                      stage_frag<CH>(stB, t8 & 3, 2 * sb2 + 1, cc, qq));
+                        acc3[o] = bf_mma<PREC>(fa, fb, acc3[o]);
+                    }
                 }
             }
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
-                if (w + NW * o < DT && !ABLE(4)) {
+                if (PREC != PREC_F32) {
+                    if (w + NW * o < DT) {
+                        // slices in pairs (one 32-row k-block per MFMA); ring of 4 slices: block sb2 + 1 in flight
+                        f32x4 xq[4] = {xb[o][0], xb[o][1], xb[o][2], zero4()};
+                        uint32_t mq[4] = {mbb[o][0], mbb[o][1], mbb[o][2], 0u};
+                        if (3 < NS) ld_xb(o, 3, xq[3], mq[3]);
+#pragma unroll
+                        for (int sb2 = 0; sb2 < NS / 2; ++sb2) {
+                            asm volatile("" ::: "memory");
+                            const BfOp fb = bf_pack<PREC>(mk_fb(o, xq[(2 * sb2) & 3], mq[(2 * sb2) & 3]),
+                                                          mk_fb(o, xq[(2 * sb2 + 1) & 3], mq[(2 * sb2 + 1) & 3]));
+                            if (2 * sb2 + 4 < NS) ld_xb(o, 2 * sb2 + 4, xq[(2 * sb2) & 3], mq[(2 * sb2) & 3]);
+                            if (2 * sb2 + 5 < NS) ld_xb(o, 2 * sb2 + 5, xq[(2 * sb2 + 1) & 3], mq[(2 * sb2 + 1) & 3]);
+#pragma unroll
+                            for (int mt = 0; mt < H1T; ++mt) {
+                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stA, mt, 2 * sb2 + 1, cc, qq));
+                                acc1[o][mt] = bf_mma<PREC>(fa, fb, acc1[o][mt]);
+                            }
+                        }
+                    }
+                } else if (w + NW * o < DT && !ABLE(4)) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         asm volatile("" ::: "memory");  // keep each slice's loads in its slice (hipcc hoists all 8 otherwise)
@@ -508,16 +598,16 @@ using namespace vpc;
 
 extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* eps, float* const* h1, float* const* h2, float* const* mean,
-                               float* const* logvar, float* const* z, int lat_pitch, int mask_augm, long B, int d,
-                               int L, void* stream) {
+                               float* const* logvar, float* const* z, int lat_pitch, int mask_augm, int precision,
+                               long B, int d, int L, void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !mean || !logvar) return VPC_ERR_ARG;
-    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0 || precision < 0 || precision > 2) return VPC_ERR_ARG;
     if (d < 1 || (mask_augm ? 2 * d : d) > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     if (lat_pitch != L && z) return VPC_ERR_ARG;  // z is only produced in the dense [B][L] layout
     EncFwdArgs a{};
     a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    const TileShape ts = tile_shape(B, npass);
+    const TileShape ts = tile_shape(B, npass, precision != PREC_F32);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
@@ -530,6 +620,17 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
     const int DT = dt_for(mask_augm ? 2 * d : d);
     const size_t lds = enc_fwd_lds(DT);
     hipStream_t s = (hipStream_t)stream;
+    if (precision != PREC_F32) {  // bf16 variants: throughput shape, vector layout (d % 4 == 0), plain encoder input
+        if (!vec || mask_augm) return VPC_ERR_SHAPE;
+#define VPC_CASE(T)                                                                                                    \
+    case T:                                                                                                            \
+        return precision == PREC_BF16X3                                                                                \
+                   ? launch(enc_fwd_kernel<T, true, false, 8, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 8, lds, s)        \
+                   : launch(enc_fwd_kernel<T, true, false, 8, PREC_BF16>, a, ts.grid_x, ts.grid_y, 8, lds, s);
+        switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+        return VPC_ERR_SHAPE;
+    }
 #define VPC_LAUNCH(T, NW)                                                                                   \
     (mask_augm ? launch(enc_fwd_kernel<T, false, true, NW>, a, ts.grid_x, ts.grid_y, NW, lds, s)            \
      : vec     ? launch(enc_fwd_kernel<T, true, false, NW>, a, ts.grid_x, ts.grid_y, NW, lds, s)            \
@@ -544,10 +645,10 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
 
 extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, const uint8_t* const* mask,
                                const float* const* h1, const float* const* h2, const float* const* dmean,
-                               const float* const* dlogvar, int lat_pitch, int mask_augm, float* partials,
-                               int* nblocks_out, long B, int d, int L, void* stream) {
+                               const float* const* dlogvar, int lat_pitch, int mask_augm, int precision,
+                               float* partials, int* nblocks_out, long B, int d, int L, void* stream) {
     if (!x || !enc_img || !mask || !h1 || !h2 || !dmean || !dlogvar || !partials) return VPC_ERR_ARG;
-    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0 || precision < 0 || precision > 2) return VPC_ERR_ARG;
     if (d < 1 || (mask_augm ? 2 * d : d) > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (lat_pitch != L && lat_pitch != 16) return VPC_ERR_ARG;
     EncBwdArgs a{};
@@ -555,7 +656,7 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG_ENC")) a.dbg = atoi(e);
 #endif
-    const TileShape ts = tile_shape(B, npass);
+    const TileShape ts = tile_shape(B, npass, precision != PREC_F32);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
@@ -567,6 +668,17 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
     if (nblocks_out) *nblocks_out = ts.nblocks;
     const int DT = dt_for(mask_augm ? 2 * d : d);
     hipStream_t s = (hipStream_t)stream;
+    if (precision != PREC_F32) {
+        if (!vec || mask_augm) return VPC_ERR_SHAPE;
+#define VPC_CASE(T)                                                                                                              \
+    case T:                                                                                                                      \
+        return precision == PREC_BF16X3                                                                                          \
+                   ? launch(enc_bwd_kernel<T, true, false, 8, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 8, enc_bwd_lds(T, 8), s)    \
+                   : launch(enc_bwd_kernel<T, true, false, 8, PREC_BF16>, a, ts.grid_x, ts.grid_y, 8, enc_bwd_lds(T, 8), s);
+        switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+        return VPC_ERR_SHAPE;
+    }
 #define VPC_LAUNCH(T, NW)                                                                                                  \
     (mask_augm ? launch(enc_bwd_kernel<T, false, true, NW>, a, ts.grid_x, ts.grid_y, NW, enc_bwd_lds(T, NW), s)            \
      : vec     ? launch(enc_bwd_kernel<T, true, false, NW>, a, ts.grid_x, ts.grid_y, NW, enc_bwd_lds(T, NW), s)            \

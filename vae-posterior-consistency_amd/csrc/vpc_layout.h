@@ -67,10 +67,11 @@ struct EncImg {
 };
 // ---- decoder image: [W4: 64 x 16][W5: 112 x 64][W6: 16*DT x 128]
 constexpr int S4 = 16;
+// (s4 = row pitch of W4 in dwords: S4 for the fp32 image, 32 for the bf16 image - one 32-wide MFMA k-block)
 struct DecImg {
     int DT, oW4, oW5, oW6, total;
-    VPC_HD explicit DecImg(int dt) {
-        DT = dt; oW4 = 0; oW5 = oW4 + H2P * S4; oW6 = oW5 + H1P * 64; total = oW6 + 16 * dt * 128;
+    VPC_HD explicit DecImg(int dt, int s4 = S4) {
+        DT = dt; oW4 = 0; oW5 = oW4 + H2P * s4; oW6 = oW5 + H1P * 64; total = oW6 + 16 * dt * 128;
     }
 };
 

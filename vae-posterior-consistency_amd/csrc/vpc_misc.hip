@@ -3,6 +3,7 @@
 //   the stand-alone fused loss kernel (K4: mask-apply / KL / consistency distance + backward seeds),
 //   Philox4x32-10 Bernoulli keep-mask and N(0,1) generators.
 #include "vpc_device.h"
+#include "vpc_bf16.h"
 #include "vpc_abi_internal.h"
 #include <cmath>
 #include <cstdlib>
@@ -30,7 +31,7 @@ int num_cus() {
     return v;
 }
 
-TileShape tile_shape(long B, int npass) {
+TileShape tile_shape(long B, int npass, bool force_big) {
     const int ncu = num_cus();
     const long t64 = (B + 63) / 64, t128 = (B + 127) / 128;
     bool small = t64 * npass <= 2L * ncu;
@@ -39,6 +40,7 @@ TileShape tile_shape(long B, int npass) {
         if (v == 64) small = true;
         if (v == 128) small = false;
     }
+    if (force_big) small = false;
     TileShape t;
     t.small = small ? 1 : 0;
     if (small) {
@@ -78,6 +80,21 @@ __global__ void pack_kernel(const float* __restrict__ flat, const int* __restric
                             int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) img[idx[i]] = flat[i];
+}
+
+// bf16 images (vpc_bf16.h): idx >= 0 is the u16 index of the hi half (lo 8 u16 further), idx < 0 encodes the dword
+// index -(idx + 1) of a value that stays fp32 (the explicit layer-1 bias)
+__global__ void pack_bf16_kernel(const float* __restrict__ flat, const int* __restrict__ idx, float* __restrict__ img,
+                                 int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = flat[i];
+    const int e = idx[i];
+    if (e < 0) { img[-(e + 1)] = v; return; }
+    unsigned short* u = reinterpret_cast<unsigned short*>(img);
+    const uint32_t hi = pk_bf16(v, 0.f) & 0xffffu;
+    u[e] = (unsigned short)hi;
+    u[e + 8] = (unsigned short)(pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu);
 }
 
 // out[i] = scale * sum_b part[b * stride + idx[i]].  A 256-thread block handles 32 parameters x 8 block
@@ -628,6 +645,58 @@ extern "C" int vpc_build_indices(int d, int L, int mask_augm, int* pack_idx, int
     return VPC_OK;
 }
 
+// ---- bf16 images (PREC_BF16X3 / PREC_BF16): same row geometry as the fp32 images (W4 rows 32 dwords instead of 16),
+// columns in the k-slot order of vpc_bf16.h.  pack_idx_bf[i] as pack_bf16_kernel reads it; img_template_bf = zeros plus
+// the constant ones of the bias chain (bf16 1.0 = 0x3F80, the layer-1 seed stays fp32).
+extern "C" int vpc_layout_sizes_bf16(int d, int L, int mask_augm, int* enc_img_floats, int* dec_img_floats) {
+    const int din = mask_augm ? 2 * d : d;
+    if (d < 1 || din > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (enc_img_floats) *enc_img_floats = EncImg(dt_for(din)).total;
+    if (dec_img_floats) *dec_img_floats = DecImg(dt_for(d), 32).total;
+    return VPC_OK;
+}
+extern "C" int vpc_build_indices_bf16(int d, int L, int mask_augm, int* pack_idx_bf, float* img_template_bf) {
+    const int din = mask_augm ? 2 * d : d;
+    if (d < 1 || din > MAX_D || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (!pack_idx_bf || !img_template_bf) return VPC_ERR_ARG;
+    const EncImg ei(dt_for(din));
+    const DecImg di(dt_for(d), 32);
+    const ParamOffsets po(d, L, din);
+    const int S1 = ei.S1, DB = ei.total;
+    std::memset(img_template_bf, 0, sizeof(float) * (size_t)(ei.total + di.total));
+    unsigned short* u = reinterpret_cast<unsigned short*>(img_template_bf);
+    const unsigned short ONE = 0x3F80;
+    auto at = [](int base_dw, int row, int f, int kp) { return 2 * base_dw + bf_elem(row, f, kp); };
+    for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
+        for (int i = 0; i < din; ++i) pack_idx_bf[po.w1 + o * din + i] = at(ei.oW1, r, i, S1);
+        pack_idx_bf[po.b1 + o] = -(ei.ob1 + r + 1);
+    }
+    img_template_bf[ei.ob1 + pos1(H1)] = 1.f;
+    for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
+        for (int i = 0; i <= H1; ++i) pack_idx_bf[(i < H1) ? po.w2 + o * H1 + i : po.b2 + o] = at(ei.oW2, r, pos1(i), 128);
+    }
+    u[at(ei.oW2, pos2(H2), pos1(H1), 128)] = ONE;
+    for (int o = 0; o < 2 * L; ++o) {
+        const int pr = row3(o, L);
+        for (int i = 0; i <= H2; ++i) pack_idx_bf[(i < H2) ? po.w3 + o * H2 + i : po.b3 + o] = at(ei.oW3, pr, pos2(i), 64);
+    }
+    for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
+        for (int i = 0; i <= L; ++i) pack_idx_bf[(i < L) ? po.w4 + o * L + i : po.b4 + o] = at(DB + di.oW4, r, i, 32);
+    }
+    u[at(DB + di.oW4, pos2(H2), L, 32)] = ONE;
+    for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
+        for (int i = 0; i <= H2; ++i) pack_idx_bf[(i < H2) ? po.w5 + o * H2 + i : po.b5 + o] = at(DB + di.oW5, r, pos2(i), 64);
+    }
+    u[at(DB + di.oW5, pos1(H1), pos2(H2), 64)] = ONE;
+    for (int o = 0; o < d; ++o)
+        for (int i = 0; i <= H1; ++i) pack_idx_bf[(i < H1) ? po.w6 + o * H1 + i : po.b6 + o] = at(DB + di.oW6, o, pos1(i), 128);
+    return VPC_OK;
+}
+
 extern "C" int vpc_num_cus(void) { return num_cus(); }
 extern "C" int vpc_max_partial_blocks(void) { return 2 * num_cus(); }
 
@@ -636,6 +705,13 @@ extern "C" int vpc_pack_weights(const float* flat_params, const int* pack_idx, f
     if (!flat_params || !pack_idx || !img || n <= 0) return VPC_ERR_ARG;
     hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat_params, pack_idx,
                        img, n);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_pack_weights_bf16(const float* flat_params, const int* pack_idx_bf, float* img_bf, int n, void* stream) {
+    if (!flat_params || !pack_idx_bf || !img_bf || n <= 0) return VPC_ERR_ARG;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat_params,
+                       pack_idx_bf, img_bf, n);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

@@ -31,7 +31,11 @@ LP = 16  # row pitch of the padded latent workspaces
 
 
 class FusedTrainer:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0,
+                 precision="f32"):
+        """precision: "f32" (v_mfma_f32_16x16x4_f32, the parity path), "bf16x3" (split-bf16 products on
+        v_mfma_f32_16x16x32_bf16: fp32-class accuracy) or "bf16" (plain bf16 inputs, fp32 accumulation and loss math);
+        the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim in (64, 128], obs_dim % 4 == 0 (csrc/vpc_bf16.h)."""
         if not isinstance(model, (Reg_VAE, vanilla_VAE)):
             raise TypeError("FusedTrainer supports Reg_VAE and vanilla_VAE")
         self.model = model
@@ -47,6 +51,18 @@ class FusedTrainer:
         flat = model.flatten_parameters()
         L.require_cuda(flat)
         self.dev = flat.device
+        if precision not in ops.PRECISIONS:
+            raise ValueError(f"precision {precision!r}: expected one of {sorted(ops.PRECISIONS)}")
+        self.precision = precision
+        self.prec = ops.PRECISIONS[precision]
+        if self.prec:
+            lay = self.lay
+            if lay.mask_augm or lay.d % 4 or not 64 < lay.d <= 128:
+                raise L.VpcError("the bf16 / bf16x3 kernels cover the plain encoder with obs_dim in (64, 128], "
+                                 "obs_dim % 4 == 0")
+            self.pidx_bf, tmpl, self.enc_img_bf = lay.bf16_tables(self.dev)
+            self.img_bf = torch.from_numpy(tmpl).to(self.dev)
+            ops.pack_weights_bf16(flat, self.pidx_bf, self.img_bf)
         n = self.lay.n_params
         # one flat bucket: [grads (n) | loss terms (9 floats)] -> a single all-reduce per step under DP
         self.bucket = torch.zeros(n + 9, device=self.dev)
@@ -140,6 +156,8 @@ class FusedTrainer:
         co = self.coefficients(epoch, alpha, beta, beta_annealing)
         img = m._images()
         enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
+        if self.prec:  # bf16 images, re-packed from the flat parameters after every optimiser step (below)
+            enc_img, dec_img = self.img_bf[:self.enc_img_bf], self.img_bf[self.enc_img_bf:]
         two = not self.vanilla
         rng0 = self.rng_offset
         # ---- random draws (mask_p and eps in ONE launch when both are drawn on the device)
@@ -179,13 +197,13 @@ class FusedTrainer:
         epss = [eq, ep] if two else [eq]
         # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
         self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
-                    None, d, Ld, LP, lay.mask_augm)
+                    None, d, Ld, LP, lay.mask_augm, self.prec)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
         nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
                           self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
-                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP)
+                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP, self.prec)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
-                          self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm)
+                          self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm, self.prec)
         # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
         self.last_blocks = (nbE, nbD)
@@ -196,6 +214,8 @@ class FusedTrainer:
                         cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
                         self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                         self.step_count, self.pidx, img, self.inv)
+            if self.prec:
+                ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
             return
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part,
                     self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"],
@@ -212,6 +232,8 @@ class FusedTrainer:
                         None if _state is None else _state[0:1],
                         loss_in=self.out9 if self.world_size > 1 else None,
                         accum=self.accum if self.world_size > 1 else None)
+            if self.prec:
+                ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
         elif self.world_size > 1:
             self.accum += self.out9[0]
 

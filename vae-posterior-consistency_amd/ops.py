@@ -49,21 +49,31 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
                               stream_ptr()), "vpc_adam_step")
 
 
-def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None, mask_augm=False):
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def pack_weights_bf16(flat_params, pack_idx_bf, img_bf):
+    check(lib().vpc_pack_weights_bf16(ptr(flat_params), ptr(pack_idx_bf), ptr(img_bf), flat_params.numel(),
+                                      stream_ptr()), "vpc_pack_weights_bf16")
+
+
+def encoder_fwd(x, enc_img, masks, eps, h1, h2, mean, logvar, z, d, Ld, lat_pitch=None, mask_augm=False, precision=0):
     n = len(masks)
     B = x.shape[0]
     check(lib().vpc_encoder_fwd(ptr(x), ptr(enc_img), n, ptr_array(masks),
                                 ptr_array(eps) if eps is not None else None, ptr_array(h1), ptr_array(h2),
                                 ptr_array(mean), ptr_array(logvar), ptr_array(z) if z is not None else None,
-                                lat_pitch or Ld, int(mask_augm), B, d, Ld, stream_ptr()), "vpc_encoder_fwd")
+                                lat_pitch or Ld, int(mask_augm), int(precision), B, d, Ld, stream_ptr()),
+          "vpc_encoder_fwd")
 
 
-def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld, lat_pitch=None, mask_augm=False):
+def encoder_bwd(x, enc_img, masks, h1, h2, dmean, dlogvar, partials, d, Ld, lat_pitch=None, mask_augm=False,
+                precision=0):
     n = len(masks)
     nb = C.c_int(0)
     check(lib().vpc_encoder_bwd(ptr(x), ptr(enc_img), n, ptr_array(masks), ptr_array(h1), ptr_array(h2),
-                                ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, int(mask_augm), ptr(partials),
-                                C.byref(nb),
+                                ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, int(mask_augm), int(precision),
+                                ptr(partials), C.byref(nb),
                                 x.shape[0], d, Ld, stream_ptr()), "vpc_encoder_bwd")
     return nb.value
 
@@ -93,13 +103,14 @@ def loss_fwd_bwd(x, xhat, maskA, maskB, cA, cE, mean, logvar, eps_ml, bq, bp, cr
 
 
 def decoder_fused(x, dec_img, maskA, maskB, cA, cE, mean, logvar, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, dmean,
-                  dlogvar, partials, loss_part, d, Ld, lat_pitch=None):
+                  dlogvar, partials, loss_part, d, Ld, lat_pitch=None, precision=0):
     n = len(maskA)
     nb = C.c_int(0)
     check(lib().vpc_decoder_fused(ptr(x), ptr(dec_img), n, ptr_array(maskA), ptr_array(maskB), farray(cA), farray(cE),
                                   ptr_array(mean), ptr_array(logvar), ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml,
-                                  inv_B, x_logvar, ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, ptr(partials),
-                                  ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_decoder_fused")
+                                  inv_B, x_logvar, ptr_array(dmean), ptr_array(dlogvar), lat_pitch or Ld, int(precision),
+                                  ptr(partials), ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()),
+          "vpc_decoder_fused")
     return nb.value
 
 
