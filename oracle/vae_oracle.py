@@ -511,3 +511,27 @@ def reward_matrix(port: "TorchPort", x, mask, M, im):
         if len(loc):
             R[loc, u] = R_lindley_chain(port, u, x, mask, M, im, loc).float()
     return R
+
+
+def active_learning_loop(x, M, forward_xmean, reward_fn):
+    """CPU restatement of the acquisition loop of active_learning_func (src/experiment_main/evaluate.py:352-456, one
+    repeat, the non-flow branch): mask starts all-unobserved; per step M forward passes give the MC imputations `im`, the
+    reward matrix R (evaluate.py:424-433 -> R_lindley_chain) picks argmax per row, the chosen feature is revealed and the
+    target MSE of M further forward passes is recorded.  `forward_xmean(mask) -> x_mean_q [n, d]` is one model.forward
+    (the reference draws its eps from the global RNG there, so callers replay recorded outputs or bring their own model);
+    `reward_fn(x, mask, im) -> R [n, d-1]`.  Returns dict(info_curve [d], action [n, d-1], R_hist [d-1, n, d-1],
+    im [d-1, M, n, d])."""
+    n, d = x.shape
+    mask = torch.zeros(n, d)
+    mse = lambda xm: torch.nn.functional.mse_loss(xm[:, -1], x[:, -1])  # noqa: E731  (evaluate.py:390)
+    curve = [torch.stack([mse(forward_xmean(mask)) for _ in range(M)]).mean()]
+    actions, R_hist, ims = [], [], []
+    for t in range(d - 1):
+        im = torch.stack([forward_xmean(mask) for _ in range(M)], 0)
+        R = reward_fn(x, mask, im)
+        i_opt = R.argmax(1)
+        mask = mask + torch.eye(d)[i_opt]
+        curve.append(torch.stack([mse(forward_xmean(mask)) for _ in range(M)]).mean())
+        actions.append(i_opt); R_hist.append(R); ims.append(im)
+    return dict(info_curve=torch.stack(curve), action=torch.stack(actions, 1).float(), R_hist=torch.stack(R_hist),
+                im=torch.stack(ims))

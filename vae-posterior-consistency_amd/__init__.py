@@ -17,7 +17,8 @@ from .eddi import Reg_EDDI, vanilla_EDDI, EDDITrainer
 from . import ops
 from . import dist as dp
 from . import active
-from .active import reward_matrix, R_lindley_chain, chaini_I, chaini_II
+from .active import (reward_matrix, R_lindley_chain, chaini_I, chaini_II, active_learning_func, active_result_paths,
+                     mc_forward)
 
 __all__ = ["Reg_VAE", "vanilla_VAE", "Reg_VAE_mask", "vanilla_VAE_mask", "FusedTrainer", "REG_notMIWAE_v2",
            "notMIWAE_myversion", "NMTrainer", "notmiwae", "eddi", "Reg_EDDI", "vanilla_EDDI", "EDDITrainer", "eval_vae_mnar", "mnar_result_path", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
