@@ -17,6 +17,8 @@ from .eddi import Reg_EDDI, vanilla_EDDI, EDDITrainer
 from . import ops
 from . import dist as dp
 from . import active
+from . import wide
+from .wide import WideTrainer
 from .active import (reward_matrix, R_lindley_chain, chaini_I, chaini_II, active_learning_func, active_result_paths,
                      mc_forward)
 

@@ -38,6 +38,9 @@ class FusedTrainer:
         the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim in (64, 128], obs_dim % 4 == 0 (csrc/vpc_bf16.h)."""
         if not isinstance(model, (Reg_VAE, vanilla_VAE)):
             raise TypeError("FusedTrainer supports Reg_VAE and vanilla_VAE")
+        if getattr(model, "_wide", False):
+            raise L.VpcError("FusedTrainer covers encoder inputs <= 128 wide and latent_dim <= 15; use wide.WideTrainer "
+                             "(harness.train does) for wider models")
         self.model = model
         self.vanilla = isinstance(model, vanilla_VAE)
         self.lr, self.betas, self.eps = lr, betas, eps

@@ -107,7 +107,11 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
     if eddi and "with_drop" in vae_type:
         fused = False  # the per-element keep-mask of the with_drop variants is applied on the API path
     if fused:
-        trainer = (NMTrainer if nm else EDDITrainer if eddi else FusedTrainer)(model, lr=0.001, seed=seed)
+        if getattr(model, "_wide", False):  # encoder input > 128 columns: the generic-GEMM step (wide.py)
+            from .wide import WideTrainer
+            trainer = WideTrainer(model, lr=0.001, seed=seed)
+        else:
+            trainer = (NMTrainer if nm else EDDITrainer if eddi else FusedTrainer)(model, lr=0.001, seed=seed)
     else:
         model.flatten_parameters()
         optimizer = torch.optim.Adam(model.parameters(), lr=0.001)  # train.py:21

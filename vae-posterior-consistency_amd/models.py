@@ -40,9 +40,11 @@ class _VAEBase(nn.Module):
                  num_estimates=1):
         super().__init__()
         enc_in = 2 * obs_dim if self.mask_augm else obs_dim
-        if enc_in > 128 or obs_dim > 128 or latent_dim > 15:
-            raise L.VpcError("the gfx950 kernels support encoder inputs <= 128 wide (obs_dim <= 128, or <= 64 for "
-                             "the mask-augmented classes) and latent_dim <= 15")
+        # encoder inputs wider than the 128 columns the register-chained kernels tile (or latent_dim > 15) run the same
+        # API on the generic GEMM kernels instead (wide.py): the reference takes any obs_dim (VAE.py:366-376)
+        self._wide = enc_in > 128 or obs_dim > 128 or latent_dim > 15
+        if latent_dim > 64 or obs_dim > 4096:
+            raise L.VpcError("supported shapes: obs_dim <= 4096, latent_dim <= 64")
         self.obs_dim = obs_dim
         self.hid_dim = hid_dim  # ignored by the reference too (VAE.py:366-376 hard-codes 100 / 50)
         self.latent_dim = latent_dim
@@ -157,17 +159,25 @@ class _VAEBase(nn.Module):
     def encoder(self, x, mask, sample=True):
         """VAE.py:387-395: returns (z, mean, logvar); eps ~ N(0,1) drawn on the device when sample=True."""
         L.require_cuda(x)
-        self._lay()
-        self._images()
         x = x.reshape(-1, self.obs_dim)
         xf = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
         m = as_mask_u8(mask.reshape(-1, self.obs_dim).to(x.device))
         eps = torch.randn(xf.shape[0], self.latent_dim, device=xf.device) if sample else None
+        if self._wide:
+            from .wide import WideEncoderFn
+            self.flatten_parameters()
+            return WideEncoderFn.apply(self, xf, m, eps, *self.trainable()[:6])
+        self._lay()
+        self._images()
         return EncoderFn.apply(self, xf, m, eps, *self.trainable()[:6])
 
     def decoder(self, z_int):
         """VAE.py:397-401: returns (x_mean, x_logvar) with x_logvar the shape-(1,) constant."""
         L.require_cuda(z_int)
+        if self._wide:
+            from .wide import WideDecoderFn
+            self.flatten_parameters()
+            return WideDecoderFn.apply(self, z_int, *self.trainable()[6:]), self.x_logvar
         self._lay()
         self._images()
         return DecoderFn.apply(self, z_int, *self.trainable()[6:]), self.x_logvar
@@ -217,7 +227,6 @@ class Reg_VAE(_VAEBase):
              alpha_annealing=True):
         """VAE.py:403-467.  One fused kernel (K4) computes every sum and, when gradients are needed, every seed."""
         L.require_cuda(x, x_recon_q, mean_q)
-        lay = self._lay()
         B, d = x.shape[0], self.obs_dim
         xlv = self._xlv(x_logvar_q)
         bw = (epoch / self.max_epoch) * beta if beta_annealing else beta
