@@ -51,8 +51,10 @@ def test_model_loader_dispatch_and_shapes():
     assert isinstance(m, vpc.Reg_VAE_mask) and m.seq_encoder[0].weight.shape == (100, 28)
     m = vpc.model_loader("train", 14, 500, 10, L, 30, "synth", TP, 1, 1, 1, "exp", "kl_reg", "vanilla_vae2_mask_augm")
     assert isinstance(m, vpc.vanilla_VAE_mask)
+    m = vpc.Reg_VAE_mask(65, 500, 10, L, TP, "exp", "kl_reg")  # 2d > 128: the generic-GEMM path (wide.py, tests/test_wide.py)
+    assert m._wide and m.seq_encoder[0].weight.shape == (100, 130)
     with pytest.raises(vpc.VpcError):
-        vpc.Reg_VAE_mask(65, 500, 10, L, TP, "exp", "kl_reg")  # 2d > 128
+        vpc.Reg_VAE(14, 500, 10, 65, TP, "exp", "kl_reg")  # latent_dim > 64
 
 
 def _model(cls, g, kind, **kw):
