@@ -229,25 +229,26 @@ int vpc_reward_matrix(const float* x, const uint8_t* mask, const float* im, cons
  * draw, decoder L->128->128 ELU + Sigmoid / Hardtanh(-10,0) heads, self-masking missingness model).  The
  * layers are generic fp32 MFMA GEMMs (any M, N, K), the loss is one fused forward+backward kernel.
  * Activation codes: 0 none, 1 ELU, 2 Sigmoid for output features < split and Hardtanh(-10,0) from split on,
- * 3 ReLU.  All matrices row-major with an explicit row pitch (ld*, in floats). */
+ * 3 ReLU.  All matrices row-major with an explicit row pitch (ld*, in floats).  `precision` as above (0 f32, 1 bf16x3,
+ * 2 bf16): the operands stay fp32 in memory and in LDS and are converted in registers - no separate weight images. */
 
 /* y[M][N] = act(x[M][K] w[N][K]^T + bias[N])            nn.Linear + activation (VAE.py:2343-2363) */
 int vpc_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long M, int N,
-                   int K, int act, int act_split, void* stream);
+                   int K, int act, int act_split, int precision, void* stream);
 
 /* dx[M][K] = ((dy * act'(y_gate)) w[N][K]) * act_prev'(x_out)     data gradient of the same layer.
  * y_gate (the layer's outputs, activation code `gate`) may be NULL when dy is already the pre-activation
  * gradient; x_out (the layer's inputs = previous layer's outputs, activation `act_prev`) may be NULL. */
 int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* w, const float* x_out, long ldx, int act_prev, float* dx, long lddx, long M, int N,
-                     int K, void* stream);
+                     int K, int precision, void* stream);
 
 /* dw[N][K] (+)= (dy * act'(y_gate))^T x,  db[N] (+)= column sums; split over M into per-workgroup partials in
  * `scratch` (vpc_linear_wgrad_scratch floats) that are summed in a fixed order.  db may be NULL. */
 long vpc_linear_wgrad_scratch(long M, int N, int K);
 int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
-                     int K, int accumulate, void* stream);
+                     int K, int accumulate, int precision, void* stream);
 
 /* z[b*K+k][:] = mean[b] + eps[b][k] * exp(logvar[b]/2), heads = [mean L | logvar L]; eps NULL -> z = mean
  * (encoder, VAE.py:2382-2391 / :2753-2765) and its backward (sum over the K replicas, plus g_heads if given). */

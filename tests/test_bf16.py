@@ -152,3 +152,65 @@ def test_unsupported_shapes_raise():
         vpc.FusedTrainer(make_model(vpc.Reg_VAE, 14, params), precision="bf16")
     with pytest.raises(ValueError):
         vpc.FusedTrainer(make_model(vpc.Reg_VAE, 14, params), precision="fp8")
+
+
+# ----------------------------------------------------------------------------------------------- config 3 (MNAR) GEMMs
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K,act", [(300, 128, 128, 1), (77, 20, 50, 0), (4000, 256, 128, 2), (33, 128, 10, 3)])
+def test_linear_kernels_vs_f32(prec, M, N, K, act):
+    """vpc_linear_fwd / _dgrad / _wgrad with precision 1 / 2 against float64 torch on ragged shapes (the operands stay fp32
+    in memory; conversion happens in registers): bf16x3 1e-5 of max, bf16 2e-2 of max."""
+    from vpc_amd import notmiwae as nm
+    p = vpc.ops.PRECISIONS[prec]
+    tol = 1e-5 if prec == "bf16x3" else 2e-2
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.2).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    y = torch.empty(M, N, device="cuda")
+    nm.linear_fwd(x, w, b, y, M, N, K, act, N // 2, precision=p)
+    pre = x.double() @ w.double().T + b.double()
+    if act == 1:
+        ref = torch.where(pre > 0, pre, torch.expm1(pre))
+    elif act == 2:
+        ref = torch.cat([torch.sigmoid(pre[:, :N // 2]), pre[:, N // 2:].clamp(-10, 0)], 1)
+    elif act == 3:
+        ref = pre.clamp(min=0)
+    else:
+        ref = pre
+    assert rel(y.cpu().numpy(), ref.cpu().numpy()) < tol
+    dx = torch.empty(M, K, device="cuda")
+    nm.linear_dgrad(dy, w, dx, M, N, K, precision=p)
+    assert rel(dx.cpu().numpy(), (dy.double() @ w.double()).cpu().numpy()) < tol
+    dw, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    nm.linear_wgrad(dy, x, dw, db, M, N, K, precision=p)
+    assert rel(dw.cpu().numpy(), (dy.double().T @ x.double()).cpu().numpy()) < tol
+    assert rel(db.cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-5  # column sums stay fp32 adds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("kind", ["reg", "van"])
+def test_mnar_trainer_vs_f32(prec, kind):
+    """NMTrainer (config 3: d = 128, K = 20, batch 128, p_missingness = 50) with bf16x3 / bf16 GEMMs against its fp32
+    run on the same injected draws: loss 1e-4 / 5e-3 relative, gradients 5e-3 / 0.15 of max (tolerances as above)."""
+    from vpc_amd import notmiwae as nm
+    d, K, Ld, B = 128, 20, 10, 128
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, d, generator=g).cuda()
+    m = (torch.rand(B, d, generator=g) < 0.7).float().cuda()
+    mp = m * (torch.rand(B, d, generator=g) < 0.5).float().cuda()
+    eps = torch.randn(2, B, K, Ld, generator=g).cuda()
+    res = {}
+    for p in ("f32", prec):
+        torch.manual_seed(5)
+        cls = nm.REG_notMIWAE_v2 if kind == "reg" else nm.notMIWAE_myversion
+        model = cls(d, 128, 10, Ld, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, precision=p)
+        tr.step(x, m, mask_p=mp if kind == "reg" else None, eps=eps, alpha=0.5, p_missingness=50)
+        res[p] = (tr.loss_value(), tr.grad.cpu().numpy().copy())
+    tl, tg = TOL[prec]
+    assert abs(res[prec][0] - res["f32"][0]) <= tl * abs(res["f32"][0]), (res[prec][0], res["f32"][0])
+    assert rel(res[prec][1], res["f32"][1]) < tg

@@ -79,9 +79,9 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert l.vpc_draw_mask(None, None, 8, 0.5, 0, 0, 0, None) == 1
     assert l.vpc_fill_normal(None, 8, 0, 0, None, 0, 0, 0, 4, None) == 1
     # MNAR path: null pointers / bad shapes are rejected before anything touches the device
-    assert l.vpc_linear_fwd(None, 4, None, None, None, 4, 8, 4, 4, 0, 0, None) == 1
-    assert l.vpc_linear_dgrad(None, 4, None, 4, 0, 0, None, None, 4, 0, None, 4, 8, 4, 4, None) == 1
-    assert l.vpc_linear_wgrad(None, 4, None, 4, 0, 0, None, 4, None, None, None, 0, 8, 4, 4, 0, None) == 1
+    assert l.vpc_linear_fwd(None, 4, None, None, None, 4, 8, 4, 4, 0, 0, 0, None) == 1
+    assert l.vpc_linear_dgrad(None, 4, None, 4, 0, 0, None, None, 4, 0, None, 4, 8, 4, 4, 0, None) == 1
+    assert l.vpc_linear_wgrad(None, 4, None, 4, 0, 0, None, 4, None, None, None, 0, 8, 4, 4, 0, 0, None) == 1
     assert l.vpc_nm_sample(None, 20, None, None, 10, 4, 2, 10, None) == 1
     assert l.vpc_linear_wgrad_scratch(0, 4, 4) == 0 and l.vpc_nm_loss_scratch(0, 4) == 0
 

@@ -17,6 +17,7 @@
 // (tools/lds_conflicts.py).  Global loads of chunk i+1 are in flight while chunk i is multiplied.
 #include "vpc_abi_internal.h"
 #include "vpc_device.h"
+#include "vpc_bf16.h"
 #include "../../include/vpc.h"
 
 namespace vpc {
@@ -147,7 +148,11 @@ __device__ __forceinline__ f32x4 frag_T(const float* __restrict__ s, int ob, int
 }
 
 // RAGGED: some 16-wide tile of the layer is empty (L = 10, 2L = 20, d = 14 ...): skip those MFMAs (wave-uniform).
-template <int MODE, bool RAGGED, int JT>
+// PREC (vpc_bf16.h): PREC_F32 = v_mfma_f32_16x16x4_f32.  PREC_BF16X3 / PREC_BF16: the same fp32 LDS tiles and fragment
+// reads; two 16-wide contraction sub-blocks are converted to one bf16 operand in registers (both operands go through the
+// same fragment functions, so any k order is consistent) and multiplied on v_mfma_f32_16x16x32_bf16 - one MFMA (three for
+// the split form) where the fp32 path issues eight.  Zero fill outside the matrices makes padded sub-blocks harmless.
+template <int MODE, bool RAGGED, int JT, int PREC = PREC_F32>
 __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
     static_assert(JT == 4 || MODE != LIN_WGRAD, "the narrow tiling is for forward / dgrad only");
     constexpr int BROWS = 32 * JT;                          // B-operand rows (batch rows) per workgroup
@@ -211,6 +216,35 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
         }
         const int n_kk = RAGGED ? min(4, (k_end - k0 + 15) / 16) : 4;  // contraction sub-blocks with real data
         if (RAGGED && (n_it == 0 || n_jt == 0)) continue;
+        if (PREC != PREC_F32) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                if (RAGGED && 2 * kp >= n_kk) break;
+                BfOp fa[IT], fb[JT];
+#pragma unroll
+                for (int t = 0; t < IT; ++t) {
+                    if (RAGGED && t >= n_it) continue;
+                    fa[t] = AT ? bf_pack<PREC>(frag_T(sA, IT * wr + t, 2 * kp, c, q), frag_T(sA, IT * wr + t, 2 * kp + 1, c, q))
+                               : bf_pack<PREC>(frag_row(sA, IT * wr + t, 2 * kp, c, q), frag_row(sA, IT * wr + t, 2 * kp + 1, c, q));
+                }
+#pragma unroll
+                for (int t = 0; t < JT; ++t) {
+                    if (RAGGED && t >= n_jt) continue;
+                    fb[t] = BT ? bf_pack<PREC>(frag_T(sB, JT * wc + t, 2 * kp, c, q), frag_T(sB, JT * wc + t, 2 * kp + 1, c, q))
+                               : bf_pack<PREC>(frag_row(sB, JT * wc + t, 2 * kp, c, q), frag_row(sB, JT * wc + t, 2 * kp + 1, c, q));
+                }
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    if (RAGGED && it >= n_it) break;
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if (RAGGED && jt >= n_jt) break;
+                        acc[it][jt] = bf_mma<PREC>(fa[it], fb[jt], acc[it][jt]);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (RAGGED && kk >= n_kk) break;
@@ -333,23 +367,30 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float*
 
 static bool vec_ok(const void* p, long ld) { return aligned16(p) && (ld % 4) == 0; }
 
-template <int MODE, bool RAGGED, int JT>
-static int launch_one(const LinArgs& a, dim3 grid, hipStream_t st) {
+template <int MODE, bool RAGGED, int JT, int PREC>
+static int launch_prec(const LinArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t LDS = (LIN_TILE + (MODE == LIN_WGRAD ? LIN_TILE : 32 * JT * 64)) * sizeof(float);
-    if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, RAGGED, JT>), LDS)) return VPC_ERR_HIP;
-    hipLaunchKernelGGL((linear_kernel<MODE, RAGGED, JT>), grid, dim3(LIN_THREADS), LDS, st, a);
+    if (!lds_attr_done(reinterpret_cast<const void*>(&linear_kernel<MODE, RAGGED, JT, PREC>), LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL((linear_kernel<MODE, RAGGED, JT, PREC>), grid, dim3(LIN_THREADS), LDS, st, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+template <int MODE, bool RAGGED, int JT>
+static int launch_one(const LinArgs& a, dim3 grid, int prec, hipStream_t st) {
+    if (prec == PREC_BF16X3) return launch_prec<MODE, RAGGED, JT, PREC_BF16X3>(a, grid, st);
+    if (prec == PREC_BF16) return launch_prec<MODE, RAGGED, JT, PREC_BF16>(a, grid, st);
+    return launch_prec<MODE, RAGGED, JT, PREC_F32>(a, grid, st);
 }
 // forward / dgrad: grid.x over batch rows (128 or 32 per workgroup), grid.y over 128 output features
 template <int MODE>
-static int launch_rows(const LinArgs& a, int out_features, hipStream_t st) {
+static int launch_rows(const LinArgs& a, int out_features, int prec, hipStream_t st) {
     // feature dimensions that leave whole 16-wide tiles / contraction sub-blocks empty take the tile-skipping build
     const bool ragged = (a.N % 64) != 0 || (a.K % 64) != 0;
     const unsigned gy = (unsigned)((out_features + 127) / 128);
     const bool narrow = (long)((a.M + 127) / 128) * gy < 2L * num_cus();
     const unsigned gx = (unsigned)((a.M + (narrow ? 31 : 127)) / (narrow ? 32 : 128));
-    if (narrow) return ragged ? launch_one<MODE, true, 1>(a, dim3(gx, gy), st) : launch_one<MODE, false, 1>(a, dim3(gx, gy), st);
-    return ragged ? launch_one<MODE, true, 4>(a, dim3(gx, gy), st) : launch_one<MODE, false, 4>(a, dim3(gx, gy), st);
+    if (narrow)
+        return ragged ? launch_one<MODE, true, 1>(a, dim3(gx, gy), prec, st) : launch_one<MODE, false, 1>(a, dim3(gx, gy), prec, st);
+    return ragged ? launch_one<MODE, true, 4>(a, dim3(gx, gy), prec, st) : launch_one<MODE, false, 4>(a, dim3(gx, gy), prec, st);
 }
 
 }  // namespace vpc
@@ -359,20 +400,22 @@ using namespace vpc;
 extern "C" {
 
 int vpc_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long M, int N,
-                   int K, int act, int act_split, void* stream) {
+                   int K, int act, int act_split, int precision, void* stream) {
     if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N || M > 0x7fffff00L) return VPC_ERR_ARG;
+    if (precision < 0 || precision > 2) return VPC_ERR_ARG;
     if (act < ACT_NONE || act > ACT_RELU) return VPC_ERR_ARG;
     LinArgs a{};
     a.A = w; a.lda = K; a.B = x; a.ldb = ldx; a.C = y; a.ldc = ldy; a.bias = bias;
     a.M = (int)M; a.N = N; a.K = K; a.act = act; a.split = act == ACT_SIGMOID_HARDTANH ? act_split : N;
     a.vecA = vec_ok(w, K); a.vecB = vec_ok(x, ldx); a.vecC = vec_ok(y, ldy);
-    return launch_rows<LIN_FWD>(a, N, (hipStream_t)stream);
+    return launch_rows<LIN_FWD>(a, N, precision, (hipStream_t)stream);
 }
 
 int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* w, const float* x_out, long ldx, int act_prev, float* dx, long lddx, long M, int N,
-                     int K, void* stream) {
+                     int K, int precision, void* stream) {
     if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K || M > 0x7fffff00L) return VPC_ERR_ARG;
+    if (precision < 0 || precision > 2) return VPC_ERR_ARG;
     if ((y_gate && ldyg < N) || (x_out && ldx < K)) return VPC_ERR_ARG;
     LinArgs a{};
     a.A = w; a.lda = K; a.B = dy; a.ldb = lddy; a.Yg = y_gate; a.ldy = ldyg; a.gate = gate;
@@ -381,7 +424,7 @@ int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     a.M = (int)M; a.N = N; a.K = K;
     a.vecA = vec_ok(w, K); a.vecB = vec_ok(dy, lddy) && (!y_gate || vec_ok(y_gate, ldyg)); a.vecC = vec_ok(dx, lddx);
     a.vecX = x_out && vec_ok(x_out, ldx);
-    return launch_rows<LIN_DGRAD>(a, K, (hipStream_t)stream);
+    return launch_rows<LIN_DGRAD>(a, K, precision, (hipStream_t)stream);
 }
 
 long vpc_linear_wgrad_scratch(long M, int N, int K) {
@@ -396,9 +439,10 @@ long vpc_linear_wgrad_scratch(long M, int N, int K) {
 
 int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
-                     int K, int accumulate, void* stream) {
+                     int K, int accumulate, int precision, void* stream) {
     if (!dy || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || M > 0x7fffff00L)
         return VPC_ERR_ARG;
+    if (precision < 0 || precision > 2) return VPC_ERR_ARG;
     if (y_gate && ldyg < N) return VPC_ERR_ARG;
     const long need = vpc_linear_wgrad_scratch(M, N, K);
     if (scratch_floats < need) return VPC_ERR_ARG;
@@ -414,7 +458,7 @@ int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
     const bool ragged = (N % 64) != 0 || (K % 64) != 0;
-    int rc = ragged ? launch_one<LIN_WGRAD, true, 4>(a, grid, st) : launch_one<LIN_WGRAD, false, 4>(a, grid, st);
+    int rc = ragged ? launch_one<LIN_WGRAD, true, 4>(a, grid, precision, st) : launch_one<LIN_WGRAD, false, 4>(a, grid, precision, st);
     if (rc != VPC_OK) return rc;
     const long n = (long)N * K + N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch,

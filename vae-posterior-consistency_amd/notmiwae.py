@@ -25,15 +25,15 @@ ACT_NONE, ACT_ELU, ACT_SIGMOID_HARDTANH, ACT_RELU = 0, 1, 2, 3
 
 
 # ------------------------------------------------------------------------------------------------ raw ops
-def linear_fwd(x, w, b, y, M, N, K, act=ACT_NONE, split=0, ldx=None, ldy=None):
-    check(lib().vpc_linear_fwd(ptr(x), ldx or K, ptr(w), ptr(b), ptr(y), ldy or N, M, N, K, act, split, stream_ptr()),
-          "vpc_linear_fwd")
+def linear_fwd(x, w, b, y, M, N, K, act=ACT_NONE, split=0, ldx=None, ldy=None, precision=0):
+    check(lib().vpc_linear_fwd(ptr(x), ldx or K, ptr(w), ptr(b), ptr(y), ldy or N, M, N, K, act, split, int(precision),
+                               stream_ptr()), "vpc_linear_fwd")
 
 
 def linear_dgrad(dy, w, dx, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=0, x_out=None, act_prev=ACT_NONE,
-                 lddy=None, lddx=None):
+                 lddy=None, lddx=None, precision=0):
     check(lib().vpc_linear_dgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(w), ptr(x_out), K,
-                                 act_prev, ptr(dx), lddx or K, M, N, K, stream_ptr()), "vpc_linear_dgrad")
+                                 act_prev, ptr(dx), lddx or K, M, N, K, int(precision), stream_ptr()), "vpc_linear_dgrad")
 
 
 _scratch = {}
@@ -49,12 +49,12 @@ def _wgrad_scratch(device, floats):
 
 
 def linear_wgrad(dy, x, dw, db, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=0, accumulate=False, lddy=None,
-                 ldx=None):
+                 ldx=None, precision=0):
     need = int(lib().vpc_linear_wgrad_scratch(M, N, K))
     sc = _wgrad_scratch(dy.device, need)
     check(lib().vpc_linear_wgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(x), ldx or K,
-                                 ptr(dw), ptr(db), ptr(sc), sc.numel(), M, N, K, int(accumulate), stream_ptr()),
-          "vpc_linear_wgrad")
+                                 ptr(dw), ptr(db), ptr(sc), sc.numel(), M, N, K, int(accumulate), int(precision),
+                                 stream_ptr()), "vpc_linear_wgrad")
 
 
 def nm_sample(heads, eps, z, B, K, Ld):
@@ -506,13 +506,20 @@ class NMTrainer:
     both passes), the fused loss kernel, the backward GEMM chain writing straight into one flat gradient buffer,
     one all-reduce of [grads | loss] under data parallelism, flat Adam."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0,
+                 precision="f32"):
+        """precision: "f32", "bf16x3" or "bf16" for the 17 GEMMs of the step (csrc/vpc_bf16.h; operands stay fp32 in
+        memory and are converted in registers); the loss kernel and Adam are fp32 in every mode."""
         if not isinstance(model, _NMBase):
             raise TypeError("NMTrainer supports REG_notMIWAE_v2 and notMIWAE_myversion")
         self.model, self.reg = model, model.regularised
         self.lr, self.betas, self.eps_adam = lr, betas, eps
         self.seed, self.rng_offset, self.step_count = seed, 0, 0
         self.pg, self.world_size, self.rank = process_group, world_size, rank
+        from .ops import PRECISIONS
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r}: expected one of {sorted(PRECISIONS)}")
+        self.precision, self.prec = precision, PRECISIONS[precision]
         flat = model.flatten_parameters()
         L.require_cuda(flat)
         self.dev = flat.device
@@ -605,13 +612,13 @@ class NMTrainer:
             self.eps.copy_(eps)
         self.rng_offset += rng_inc
         # ---- forward
-        t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU)
-        t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU)
-        t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE)
+        t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU, precision=self.prec)
+        t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU, precision=self.prec)
+        t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE, precision=self.prec)
         t("sample", nm_sample, self.heads, self.eps if reg else self.eps[0], self.z, R, K, Ld)
-        t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU)
-        t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU)
-        t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d)
+        t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU, precision=self.prec)
+        t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU, precision=self.prec)
+        t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d, precision=self.prec)
         # ---- loss + output-side gradients
         Y, G = self.Y, self.G
         t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
@@ -622,19 +629,19 @@ class NMTrainer:
           B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
         # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
         g = self.g
-        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID)
-        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU)
-        t("dec_wgrad2", linear_wgrad, self.dg2, self.g1, g["Wd2"], g["bd2"], M, HID, HID)
-        t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU)
-        t("dec_wgrad1", linear_wgrad, self.dg1, self.z, g["Wd1"], g["bd1"], M, HID, Ld)
-        t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld)
+        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID, precision=self.prec)
+        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, precision=self.prec)
+        t("dec_wgrad2", linear_wgrad, self.dg2, self.g1, g["Wd2"], g["bd2"], M, HID, HID, precision=self.prec)
+        t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU, precision=self.prec)
+        t("dec_wgrad1", linear_wgrad, self.dg1, self.z, g["Wd1"], g["bd1"], M, HID, Ld, precision=self.prec)
+        t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld, precision=self.prec)
         t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
           K, Ld)
-        t("enc_bwd", linear_wgrad, self.dht, self.h2, g["Wh"], g["bh"], R, 2 * Ld, HID)
-        t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU)
-        t("enc_bwd", linear_wgrad, self.dh2, self.h1, g["We2"], g["be2"], R, HID, HID)
-        t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU)
-        t("enc_bwd", linear_wgrad, self.dh1, self.xin, g["We1"], g["be1"], R, HID, d)
+        t("enc_bwd", linear_wgrad, self.dht, self.h2, g["Wh"], g["bh"], R, 2 * Ld, HID, precision=self.prec)
+        t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU, precision=self.prec)
+        t("enc_bwd", linear_wgrad, self.dh2, self.h1, g["We2"], g["be2"], R, HID, HID, precision=self.prec)
+        t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU, precision=self.prec)
+        t("enc_bwd", linear_wgrad, self.dh1, self.xin, g["We1"], g["be1"], R, HID, d, precision=self.prec)
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
