@@ -209,6 +209,20 @@ int vpc_draw_step(const uint8_t* mask_in, uint8_t* mask_out, long n_mask, float 
 int vpc_fill_normal(float* out, long n, unsigned long long seed, unsigned long long offset, const long long* state,
                     long rows_local, long rows_global, long row_lo, int pitch, void* stream);
 
+/* ---- data parallel: the step's ONE collective on the caller's stream (RCCL over xGMI) -------
+ * The reference has no distributed code; these entry points exist so that the flat bucket [gradients | loss terms]
+ * (37 548 + 9 floats) is all-reduced as an ordinary node of the compute stream - no hop to a communication stream,
+ * capturable in the same HIP graph as vpc_reduce_step and vpc_adam_step.  librccl is opened lazily (dlopen).
+ *   vpc_rccl_unique_id   rank 0: 128-byte ncclUniqueId into HOST memory; the caller ships it to the other ranks
+ *                        (the Python host uses the torch.distributed process group it already has for that)
+ *   vpc_rccl_comm_init   every rank, collectively: ncclCommInitRank on the CURRENT device -> opaque communicator
+ *   vpc_allreduce_flat   in-place ncclAllReduce(sum, fp32) of bucket[0, count) on `stream`
+ *   vpc_rccl_comm_destroy */
+int vpc_rccl_unique_id(void* id128_host);
+int vpc_rccl_comm_init(const void* id128_host, int nranks, int rank, void** comm_out);
+int vpc_allreduce_flat(void* comm, float* bucket, long count, void* stream);
+int vpc_rccl_comm_destroy(void* comm);
+
 /* ---- active variable selection reward (config 5) -------------------------------------------------------
  * Replaces the candidate loop of active_learning_func (src/experiment_main/evaluate.py:424-433) and the
  * functions it calls, R_lindley_chain / chaini_I / chaini_II (evaluate.py:514-634): for every row n and every

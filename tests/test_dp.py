@@ -335,3 +335,45 @@ def test_two_rank_eddi_trainer_matches_single_process():
         assert abs(tr.loss_value() - losses2[i]) <= 5e-6 * abs(losses2[i]), (i, tr.loss_value(), losses2[i])
     flat1 = m._flat.cpu().numpy()
     assert np.max(np.abs(flat1 - flat2)) <= 3e-5 * np.max(np.abs(flat1))
+
+
+# ----------------------------------------------------------------------------------------------- RCCL on the compute stream
+@pytest.mark.gpu
+def test_rccl_flat_allreduce_on_compute_stream_single_rank():
+    """The C-ABI binding of ncclAllReduce (vpc_allreduce_flat, dist.FlatAllReduce) with a ONE-rank communicator - all a
+    one-GPU box can host: the unique id / ncclCommInitRank / in-place all-reduce calls work, run on torch's current
+    stream, and the data-parallel tail of the fused step (reduce_step -> all-reduce -> adam_step) through it equals the
+    single fused launch bit for bit, eagerly and replayed from ONE captured HIP graph (the collective is a graph node).
+    Multi-rank RCCL needs more than one GPU; the sharding arithmetic is covered by the gloo tests above."""
+    dev = torch.device("cuda:0")
+    coll = vpc.dp.FlatAllReduce(1, 0, dev)
+    t = torch.arange(1000, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # issued on the CURRENT stream, whichever that is
+        t.mul_(2.0)
+        coll(t)
+        t.add_(1.0)
+    side.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32) * 2 + 1)
+    d, B = 128, 1024
+    x, mask, _, _, _ = _inputs(B, d, seed=21)
+    x, mask = x.to(dev), mask.to(dev)
+    tr0, m0 = _single_trainer(d, B, dev, seed=3)
+    tr1, m1 = _single_trainer(d, B, dev, seed=3)
+    tr1.collective, tr1._coll_ready, tr1.dp = coll, True, True
+    tr2, m2 = _single_trainer(d, B, dev, seed=3)
+    tr2.collective, tr2._coll_ready, tr2.dp = coll, True, True
+    for i in range(4):
+        tr0.step(x, mask, alpha=0.9, epoch=i + 1)
+        tr1.step(x, mask, alpha=0.9, epoch=i + 1)
+        tr2.step_graph(x, mask, alpha=0.9, epoch=1)
+        assert tr0.loss_value() == tr1.loss_value()
+    assert torch.equal(m0._flat, m1._flat)
+    assert abs(tr0.epoch_total() - tr1.epoch_total()) < 1e-3
+    # graph replay (steps 2..4 are replays; epoch fixed because beta_annealing is off): same parameters as eager
+    tr3, m3 = _single_trainer(d, B, dev, seed=3)
+    for i in range(4):
+        tr3.step(x, mask, alpha=0.9, epoch=1)
+    assert torch.equal(m2._flat, m3._flat)
+    assert getattr(tr2, "_graph", None) is not None
+    coll.close()

@@ -59,6 +59,10 @@ _PROTOS = {
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, L_, P],
     "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, L_, L_, L_, L_, I, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P, L_, L_, L_, I, P],
+    "vpc_rccl_unique_id": [P],
+    "vpc_rccl_comm_init": [P, I, I, PP],
+    "vpc_allreduce_flat": [P, P, L_, P],
+    "vpc_rccl_comm_destroy": [P],
     "vpc_reward_scratch": [I, I, I, C.POINTER(L_), C.POINTER(L_), C.POINTER(L_)],
     "vpc_reward_matrix": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     # MNAR path (config 3)

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_dec8.hip", "vpc_misc.hip", "vpc_reward.hip", "vpc_gemm.hip", "vpc_nm.hip", "vpc_eddi.hip"]
+SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_dec8.hip", "vpc_misc.hip", "vpc_reward.hip", "vpc_gemm.hip", "vpc_nm.hip", "vpc_eddi.hip", "vpc_rccl.hip"]
 HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h", "vpc_dec_args.h", "../../include/vpc.h"]
 LIB = os.path.join(HERE, "libvpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -56,7 +56,7 @@ def build(force=False, asm=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda s: _compile(s, asm), SRCS))
     if _newer(LIB, objs):
-        r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, cwd=HERE,
+        r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"], cwd=HERE,
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

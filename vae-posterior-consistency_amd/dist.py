@@ -1,12 +1,22 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
+"""Data-parallel plumbing: one process per GPU, rows sharded contiguously, ONE all-reduce per step.
 
-The model is 150 KB, so the per-step exchange is ONE latency-bound all-reduce of the flat bucket
-[37 548 gradients | 9 loss terms] issued on the compute stream by FusedTrainer.step.  Rows are sharded
-contiguously; every rank normalises by the GLOBAL batch so that SUM over ranks equals the single-process
-result on the concatenated batch (src/models/VAE.py:452 divides by x.shape[0]).
+The model is 150 KB, so the per-step exchange is a single latency-bound all-reduce of the flat bucket
+[37 548 gradients | 9 loss terms].  Every rank normalises by the GLOBAL batch so that SUM over ranks equals the
+single-process result on the concatenated batch (src/models/VAE.py:452 divides by x.shape[0]); Philox counters of the
+per-step draws are keyed by the global row (fused.py), so results do not depend on the world size.
+
+Two carriers for the bucket:
+  * `FlatAllReduce` (default when the process group is NCCL): ncclAllReduce bound straight from librccl through the C ABI
+    (vpc_allreduce_flat) and issued on the COMPUTE stream - no hop to torch's communication stream and back, and the
+    whole tail reduce_step -> all-reduce -> adam_step is capturable in one HIP graph (FusedTrainer.step_graph under data
+    parallelism).  The communicator is created with ncclCommInitRank; the 128-byte unique id travels from rank 0 through
+    the torch.distributed process group that torchrun set up.
+  * torch.distributed.all_reduce on the process group (gloo on CPU boxes / rehearsals on one GPU, or NCCL when
+    VPC_DP_COLLECTIVE=torch).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import torch
@@ -53,8 +63,72 @@ def shutdown():
         dist.destroy_process_group()
 
 
-def allreduce_bucket(bucket: torch.Tensor, group=None):
-    """The step's single collective (sum).  No-op for a single process."""
+class FlatAllReduce:
+    """In-place sum of a flat fp32 CUDA tensor over the ranks with ncclAllReduce (RCCL) on torch's CURRENT stream."""
+
+    def __init__(self, nranks: int, rank: int, device, group=None):
+        from . import _lib as L
+        self._L = L
+        lib = L.lib()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            L.check(lib.vpc_rccl_unique_id(C.cast(buf, C.c_void_p)), "vpc_rccl_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if nranks > 1:  # ship the id through the existing process group (device tensor for NCCL, host tensor for gloo)
+            dev_pg = dist.get_backend(group) == "nccl"
+            t = uid.to(device) if dev_pg else uid
+            dist.broadcast(t, src=0, group=group)
+            uid = t.cpu()
+        raw = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+        comm = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(lib.vpc_rccl_comm_init(C.cast(raw, C.c_void_p), nranks, rank, C.byref(comm)), "vpc_rccl_comm_init")
+        self.comm, self.nranks, self.rank = comm, nranks, rank
+
+    def __call__(self, bucket: torch.Tensor):
+        L = self._L
+        L.require_cuda(bucket)
+        if bucket.dtype != torch.float32 or not bucket.is_contiguous():
+            raise L.VpcError("FlatAllReduce takes a contiguous fp32 tensor")
+        L.check(L.lib().vpc_allreduce_flat(self.comm, L.ptr(bucket), bucket.numel(), L.stream_ptr()), "vpc_allreduce_flat")
+        return bucket
+
+    def close(self):
+        if self.comm:
+            self._L.lib().vpc_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+def make_collective(world_size: int, rank: int, device, group=None):
+    """The carrier of the per-step bucket: FlatAllReduce (RCCL on the compute stream) when the process group is NCCL
+    (and VPC_DP_COLLECTIVE != 'torch'), else None = torch.distributed.all_reduce on the group."""
+    if world_size <= 1 or not dist.is_initialized():
+        return None
+    if os.environ.get("VPC_DP_COLLECTIVE", "rccl") == "torch" or dist.get_backend(group) != "nccl":
+        return None
+    # all ranks must take the same carrier: agree on success before using the RCCL communicator
+    coll, ok = None, 1.0
+    try:
+        coll = FlatAllReduce(world_size, rank, device, group)
+    except Exception as e:  # librccl missing / communicator creation failed on this rank
+        import sys
+        print(f"[vpc] RCCL communicator unavailable on rank {rank} ({e}); using torch.distributed.all_reduce", file=sys.stderr)
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if float(flag.item()) < 0.5:
+        if coll is not None:
+            coll.close()
+        return None
+    return coll
+
+
+def allreduce_bucket(bucket: torch.Tensor, group=None, collective=None):
+    """The step's single collective (sum): through `collective` (FlatAllReduce) when given, else torch.distributed.
+    No-op for a single process."""
+    if collective is not None:
+        return collective(bucket)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     return bucket

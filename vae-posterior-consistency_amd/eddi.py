@@ -358,9 +358,12 @@ class EDDITrainer:
         linear_dgrad(self.dh1, W1, self.dagg, R, H1, K)
         eddi_front_bwd(x, masks[0], self.AC, self.dagg, E, tb, Wp, g[12], g[13], g[14], g[15], B, d, K,
                        mask2_u8=masks[1] if two else None, scratch=self.front_scratch)
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
+            from . import dist as dp_mod
+            if not getattr(self, "_coll_ready", False):
+                self.collective = dp_mod.make_collective(self.world_size, self.rank, self.dev, self.pg)
+                self._coll_ready = True
+            dp_mod.allreduce_bucket(self.bucket, self.pg, self.collective)
         self.step_count += 1
         dp = self.world_size > 1  # the Adam launch also adds the all-reduced loss to the epoch accumulator
         ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],

@@ -23,6 +23,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import dist as dp_mod
 from . import ops
 from .models import MAX_EPOCH, Reg_VAE, vanilla_VAE
 from .ops import H1P, H2P, as_mask_u8
@@ -32,10 +33,13 @@ LP = 16  # row pitch of the padded latent workspaces
 
 class FusedTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=1, rank=0,
-                 precision="f32"):
+                 precision="f32", collective=None):
         """precision: "f32" (v_mfma_f32_16x16x4_f32, the parity path), "bf16x3" (split-bf16 products on
         v_mfma_f32_16x16x32_bf16: fp32-class accuracy) or "bf16" (plain bf16 inputs, fp32 accumulation and loss math);
-        the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim in (64, 128], obs_dim % 4 == 0 (csrc/vpc_bf16.h)."""
+        the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim in (64, 128], obs_dim % 4 == 0 (csrc/vpc_bf16.h).
+        collective: carrier of the per-step bucket under data parallelism (dist.FlatAllReduce = ncclAllReduce on the
+        compute stream); None = chosen on the first multi-rank step by dist.make_collective (RCCL when the process group
+        is NCCL, torch.distributed.all_reduce otherwise)."""
         if not isinstance(model, (Reg_VAE, vanilla_VAE)):
             raise TypeError("FusedTrainer supports Reg_VAE and vanilla_VAE")
         if getattr(model, "_wide", False):
@@ -50,6 +54,10 @@ class FusedTrainer:
         self.pg = process_group
         self.world_size = world_size
         self.rank = rank  # data parallel: this rank's rows are [rank * B, (rank + 1) * B) of the global batch by default
+        self.collective = collective
+        self._coll_ready = collective is not None
+        # the data-parallel tail (reduce_step -> all-reduce -> adam_step) instead of the single fused launch
+        self.dp = world_size > 1 or collective is not None
         self.lay = model._lay()
         flat = model.flatten_parameters()
         L.require_cuda(flat)
@@ -210,7 +218,7 @@ class FusedTrainer:
         # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
         self.last_blocks = (nbE, nbD)
-        if update and self.world_size == 1 and _state is None:
+        if update and not self.dp and _state is None:
             self.step_count += 1
             ops.reduce_step_adam(self.partE, nbE, lay.enc_part, self.partD, nbD,
                         lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
@@ -223,9 +231,9 @@ class FusedTrainer:
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part,
                     self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"],
                     co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9,
-                    self.accum if self.world_size == 1 else None, _state,
+                    None if self.dp else self.accum, _state,
                     self.rng_offset - rng0 if _state is not None else 0, self.inv)
-        if self.world_size > 1:
+        if self.dp:
             self._allreduce()
         if update:
             self.step_count += 1
@@ -233,11 +241,10 @@ class FusedTrainer:
             ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                         self.lr, self.betas[0], self.betas[1], self.eps, self.pidx, img,
                         None if _state is None else _state[0:1],
-                        loss_in=self.out9 if self.world_size > 1 else None,
-                        accum=self.accum if self.world_size > 1 else None)
+                        loss_in=self.out9 if self.dp else None, accum=self.accum if self.dp else None)
             if self.prec:
                 ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
-        elif self.world_size > 1:
+        elif self.dp:
             self.accum += self.out9[0]
 
     # ------------------------------------------------------------------ HIP-graph replay of the step
@@ -246,8 +253,10 @@ class FusedTrainer:
         of six kernel launches - what matters at the reference's own batch sizes (64 / 128), where the step is
         launch-bound.  Step count and Philox offsets live on the device (`state`), since kernel arguments are
         frozen in a graph.  Draws are always on the device; the first call with a new (shape, coefficients) runs
-        one eager step and captures.  Single process only (data parallel falls back to step())."""
-        if self.world_size > 1:
+        one eager step and captures.  Under data parallelism the graph holds reduce_step -> ncclAllReduce -> adam_step
+        when the bucket travels through dist.FlatAllReduce (RCCL on the compute stream); with a torch.distributed
+        carrier (gloo) it falls back to step()."""
+        if self.dp and not isinstance(self._collective(), dp_mod.FlatAllReduce):
             return self.step(x, mask, epoch=epoch, alpha=alpha, beta=beta, beta_annealing=beta_annealing,
                              p_missingness=p_missingness)
         L.require_cuda(x)
@@ -280,12 +289,17 @@ class FusedTrainer:
         self.step_count += 1
         self.rng_offset += self._graph_rng_inc
 
+    def _collective(self):
+        if not self._coll_ready:
+            self.collective = dp_mod.make_collective(self.world_size, self.rank, self.dev, self.pg)
+            self._coll_ready = True
+        return self.collective
+
     def _allreduce(self):
-        """ONE collective per step over the flat bucket [grads | loss terms] (RCCL over xGMI when the process
-        group is NCCL).  Every term is already normalised by the GLOBAL batch, so a plain SUM is the result
-        of the concatenated batch."""
-        import torch.distributed as dist
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        """ONE collective per step over the flat bucket [grads | loss terms]: ncclAllReduce (RCCL over xGMI) on the
+        compute stream when the process group is NCCL, torch.distributed.all_reduce otherwise (dist.py).  Every term
+        is already normalised by the GLOBAL batch, so a plain SUM is the result of the concatenated batch."""
+        dp_mod.allreduce_bucket(self.bucket, self.pg, self._collective())
 
     def loss_value(self) -> float:
         """Loss of the last step (host sync)."""

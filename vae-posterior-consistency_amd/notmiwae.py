@@ -642,9 +642,12 @@ class NMTrainer:
         t("enc_bwd", linear_wgrad, self.dh2, self.h1, g["We2"], g["be2"], R, HID, HID, precision=self.prec)
         t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU, precision=self.prec)
         t("enc_bwd", linear_wgrad, self.dh1, self.xin, g["We1"], g["be1"], R, HID, d, precision=self.prec)
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
+            from . import dist as dp_mod
+            if not getattr(self, "_coll_ready", False):
+                self.collective = dp_mod.make_collective(self.world_size, self.rank, self.dev, self.pg)
+                self._coll_ready = True
+            dp_mod.allreduce_bucket(self.bucket, self.pg, self.collective)
         self.step_count += 1
         from .ops import adam_step
         t("adam", adam_step, m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,

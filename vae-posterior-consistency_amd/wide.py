@@ -172,9 +172,12 @@ class WideTrainer:
             self.grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
         self.loss.copy_(tl.detach().reshape(1))
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
+            from . import dist as dp_mod
+            if not getattr(self, "_coll_ready", False):
+                self.collective = dp_mod.make_collective(self.world_size, self.rank, self.dev, self.pg)
+                self._coll_ready = True
+            dp_mod.allreduce_bucket(self.bucket, self.pg, self.collective)
         self.step_count += 1
         ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
                       self.betas[1], self.eps, loss_in=self.loss, accum=self.accum)
