@@ -73,13 +73,15 @@ class FlatAllReduce:
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_char * 128)()
-            L.check(lib.vpc_rccl_unique_id(C.cast(buf, C.c_void_p)), "vpc_rccl_unique_id")
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if lib.vpc_rccl_unique_id(C.cast(buf, C.c_void_p)) == 0:  # on failure the all-zero id tells every rank
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
         if nranks > 1:  # ship the id through the existing process group (device tensor for NCCL, host tensor for gloo)
             dev_pg = dist.get_backend(group) == "nccl"
             t = uid.to(device) if dev_pg else uid
             dist.broadcast(t, src=0, group=group)
             uid = t.cpu()
+        if not bool(uid.any()):
+            raise L.VpcError("ncclGetUniqueId failed on rank 0 (librccl not loadable?)")
         raw = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
         comm = C.c_void_p()
         with torch.cuda.device(device):
