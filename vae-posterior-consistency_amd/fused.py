@@ -89,6 +89,7 @@ class FusedTrainer:
         self.pidx, self.gidx = self.lay.device_tables(self.dev)
         self.inv = self.lay.inverse_maps(self.dev)  # caller-owned maps for the layout-order gradient reduction
         self._ws_B = None
+        self._pads = {}
         self.timers = None  # bench.py sets this to {} to collect per-kernel HIP event pairs
         self.timer_every = 8  # ... on every 8th step only: an event pair costs ~5 us of GPU idle time per kernel
         self._timer_tick = 0
@@ -100,10 +101,19 @@ class FusedTrainer:
             off += p.numel()
 
     # ------------------------------------------------------------------
-    def _workspaces(self, B):
-        if self._ws_B == B:
+    def _pad_cols(self, t, dk, slot):
+        """[B, d] -> zero-padded [B, dk] (a persistent buffer per input slot)."""
+        key = (slot, t.shape[0], dk, t.dtype)
+        buf = self._pads.get(key)
+        if buf is None:
+            buf = self._pads[key] = torch.zeros(t.shape[0], dk, dtype=t.dtype, device=self.dev)
+        buf[:, :t.shape[1]].copy_(t)
+        return buf
+
+    def _workspaces(self, B, d):
+        if self._ws_B == (B, d):
             return
-        dev, Ld, d = self.dev, self.lay.L, self.lay.d
+        dev, Ld = self.dev, self.lay.L
         np_ = 1 if self.vanilla else 2
         self.h1 = [torch.empty(B, H1P, device=dev) for _ in range(np_)]
         self.h2 = [torch.empty(B, H2P, device=dev) for _ in range(np_)]
@@ -114,7 +124,7 @@ class FusedTrainer:
         self.dlogvar = [torch.empty(B, LP, device=dev) for _ in range(np_)]
         self.eps_buf = torch.empty(3, B, LP, device=dev)
         self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
-        self._ws_B = B
+        self._ws_B = (B, d)
 
     def _timed(self, name, fn, *args):
         """Run one launch; with timers enabled bracket it with events on the launch stream."""
@@ -158,7 +168,16 @@ class FusedTrainer:
         B, d, Ld = x.shape[0], lay.d, lay.L
         x = ops._f32c(x)
         mask = as_mask_u8(mask)
-        self._workspaces(B)
+        # Row pitch of the kernels' x / mask arrays.  obs_dim % 4 != 0 would take the scalar-load kernel variants (the ones
+        # that spill, profiles/r01_kernel_resources.txt): instead the inputs are copied into arrays padded to a multiple of
+        # 4 columns with mask 0 in the padding - never observed, so it adds nothing to any sum or gradient, and the weight
+        # images already hold zeros for the columns / rows past obs_dim - and the 16-byte-vector variants run on those.
+        dk = d if (d % 4 == 0 or lay.mask_augm) else 4 * ((d + 3) // 4)
+        if dk != d:
+            x, mask = self._pad_cols(x, dk, 0), self._pad_cols(mask, dk, 1)
+            if mask_p is not None:
+                mask_p = self._pad_cols(as_mask_u8(mask_p), dk, 2)
+        self._workspaces(B, dk)
         Bg = global_batch if global_batch is not None else B * self.world_size
         if row_lo is None:
             row_lo = self.rank * B if self.world_size > 1 else 0
@@ -180,14 +199,14 @@ class FusedTrainer:
         eps_shard = (B, Bg, row_lo, LP)
         if two and mask_p is None:
             off_m = self.rng_offset
-            self.rng_offset += (Bg * d + 7) // 8 + 1
+            self.rng_offset += (Bg * dk + 7) // 8 + 1
             if draw_eps:
                 ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
-                              self.rng_offset, _state, row_lo * d, eps_shard)
+                              self.rng_offset, _state, row_lo * dk, eps_shard)
                 self.rng_offset += n_eps_groups
                 draw_eps = False
             else:
-                ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, off_m, row_lo * d)
+                ops.draw_mask(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, self.seed, off_m, row_lo * dk)
             mask_p = self.mask_p_buf
         elif two:
             mask_p = as_mask_u8(mask_p)
@@ -208,13 +227,13 @@ class FusedTrainer:
         epss = [eq, ep] if two else [eq]
         # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
         self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
-                    None, d, Ld, LP, lay.mask_augm, self.prec)
+                    None, dk, Ld, LP, lay.mask_augm, self.prec)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
         nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
                           self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
-                          self.dmean, self.dlogvar, self.partD, self.loss_part, d, Ld, LP, self.prec)
+                          self.dmean, self.dlogvar, self.partD, self.loss_part, dk, Ld, LP, self.prec)
         nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
-                          self.dlogvar, self.partE, d, Ld, LP, lay.mask_augm, self.prec)
+                          self.dlogvar, self.partE, dk, Ld, LP, lay.mask_augm, self.prec)
         # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
         self.last_blocks = (nbE, nbD)
