@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vpc_amd as vpc
 
-B, d, L = 65536, 128, 10
+B, d, L = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 128, 10
 dev = torch.device("cuda")
 torch.manual_seed(0)
 m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "bench", "kl_reg").to(dev)
@@ -43,6 +43,6 @@ for i in range(25):
 torch.cuda.synchronize()
 k4_ms = statistics.median(a.elapsed_time(b) for a, b in ev[5:])
 alg = 3216 * B
-print(json.dumps({"api_path_ms_per_step": api_ms, "api_path_samples_per_s": B / api_ms * 1e3,
+print(json.dumps({"B": B, "api_path_ms_per_step": api_ms, "api_path_samples_per_s": B / api_ms * 1e3,
                   "k4_loss_call_ms": k4_ms, "k4_algorithmic_bytes": alg,
                   "k4_GBps_incl_host_glue": alg / (k4_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000}))

@@ -72,11 +72,16 @@ class _VAEBase(nn.Module):
 
     # ------------------------------------------------------------------ parameter plumbing
     def trainable(self):
-        """The 12 trainable tensors in state_dict (= flat) order."""
-        out = []
-        for name in _ENC + _DEC:
-            mod = self.get_submodule(name)
-            out += [mod.weight, mod.bias]
+        """The 12 trainable tensors in state_dict (= flat) order.  (Cached: nn.Module attribute lookups cost ~0.4 ms per
+        training step on the API path, which is host-bound at the reference's batch sizes; .to() / load_state_dict keep
+        the Parameter objects.)"""
+        out = self.__dict__.get("_trainable_cache")
+        if out is None or out[0] is not self.seq_encoder[0].weight:
+            out = []
+            for name in _ENC + _DEC:
+                mod = self.get_submodule(name)
+                out += [mod.weight, mod.bias]
+            self.__dict__["_trainable_cache"] = out
         return out
 
     def _lay(self):
@@ -88,7 +93,11 @@ class _VAEBase(nn.Module):
         """Make the 12 trainable tensors views of ONE flat fp32 buffer (state_dict order).  Idempotent; call again
         after .to(device).  Returns the flat buffer."""
         ps = self.trainable()
-        flat = getattr(self, "_flat", None)
+        flat = self.__dict__.get("_flat")
+        # fast path: first and last parameter still sit where the flat buffer puts them
+        if flat is not None and ps[0].data_ptr() == flat.data_ptr() and \
+                ps[-1].data_ptr() == flat.data_ptr() + 4 * (flat.numel() - ps[-1].numel()) and flat.device == ps[0].device:
+            return flat
         off = 0
         ok = flat is not None and flat.device == ps[0].device
         if ok:
@@ -111,9 +120,9 @@ class _VAEBase(nn.Module):
         """What the packed image was built from: the version counters of the 12 parameters AND of the flat buffer they
         are views of (an in-place write through `_flat` - dist.broadcast, a raw kernel - bumps only the latter).  Writes
         through `p.data` bump neither: call invalidate_images() after those."""
-        flat = getattr(self, "_flat", None)
-        return tuple(p._version for p in self.trainable()) + (self.seq_encoder[0].weight.data_ptr(),
-                                                               -1 if flat is None else flat._version)
+        flat = self.__dict__.get("_flat")
+        ps = self.trainable()
+        return tuple(p._version for p in ps) + (ps[0].data_ptr(), -1 if flat is None else flat._version)
 
     def invalidate_images(self):
         """Force a re-pack of the weight images on the next forward (after writing parameters through `.data`)."""
@@ -216,9 +225,23 @@ class Reg_VAE(_VAEBase):
 
     def forward(self, data, mask, mask_p, stage="train"):
         # VAE.py:496-507 - q pass first (eps_q), then p pass (eps_p); p outputs are returned first
-        z_q, mean_q, logvar_q = self.encoder(data, mask)
+        if type(self).encoder is _VAEBase.encoder and not self._wide:
+            # both encoder passes as one autograd node / one launch each way (ops.RegEncoderFn); eps_q is drawn before
+            # eps_p, as the two rsample() calls of the reference are
+            L.require_cuda(data)
+            self._images()
+            x = data.reshape(-1, self.obs_dim)
+            xf = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+            mq = as_mask_u8(mask.reshape(-1, self.obs_dim).to(x.device))
+            mp = as_mask_u8(mask_p.reshape(-1, self.obs_dim).to(x.device))
+            eps_q = torch.randn(xf.shape[0], self.latent_dim, device=xf.device)  # two draws, as the two rsample() calls
+            eps_p = torch.randn(xf.shape[0], self.latent_dim, device=xf.device)
+            z_q, mean_q, logvar_q, z_p, mean_p, logvar_p = ops.RegEncoderFn.apply(self, xf, mq, mp, eps_q, eps_p,
+                                                                                 *self.trainable()[:6])
+        else:  # subclasses with their own encoder (EDDI) and the wide path: pass by pass
+            z_q, mean_q, logvar_q = self.encoder(data, mask)
+            z_p, mean_p, logvar_p = self.encoder(data, mask_p)
         x_mean_q, x_logvar_q = self.decoder(z_q)
-        z_p, mean_p, logvar_p = self.encoder(data, mask_p)
         x_mean_p, x_logvar_p = self.decoder(z_p)
         return mean_p, logvar_p, x_mean_p, x_logvar_p, mean_q, logvar_q, x_mean_q, x_logvar_q
 

@@ -212,6 +212,57 @@ class EncoderFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class RegEncoderFn(torch.autograd.Function):
+    """Both encoder passes of Reg_VAE.forward (VAE.py:496-507: q with `mask`, p with `mask_p`) as ONE autograd node:
+    one vpc_encoder_fwd launch forward (x is read once per tile for both passes), one vpc_encoder_bwd launch + one
+    reduction backward - half the launches of two EncoderFn nodes, which is what the API path is bound by at the
+    reference's batch sizes.  (x, mask, mask_p, eps_q, eps_p, 6 encoder tensors) -> (z_q, mean_q, logvar_q, z_p, mean_p,
+    logvar_p)."""
+
+    @staticmethod
+    def forward(ctx, model, x, mq_u8, mp_u8, eps_q, eps_p, *weights):
+        lay = model._lay()
+        d, Ld = lay.d, lay.L
+        require_cuda(x, mq_u8, mp_u8, eps_q, eps_p, *weights)
+        B, dev = x.shape[0], x.device
+        h1 = [torch.empty(B, H1P, device=dev) for _ in range(2)]
+        h2 = [torch.empty(B, H2P, device=dev) for _ in range(2)]
+        lat = torch.empty(2, 3, B, Ld, device=dev)  # [pass][mean | logvar | z]
+        mean, logvar, z = [lat[0, 0], lat[1, 0]], [lat[0, 1], lat[1, 1]], [lat[0, 2], lat[1, 2]]
+        encoder_fwd(x, model._enc_img(), [mq_u8, mp_u8], [eps_q, eps_p], h1, h2, mean, logvar, z, d, Ld,
+                    mask_augm=lay.mask_augm)
+        # d z / d logvar = eps * exp(logvar / 2) / 2 for both passes (None eps: z = mean)
+        eps = torch.stack([e if e is not None else torch.zeros(B, Ld, device=dev) for e in (eps_q, eps_p)])
+        fac = eps * torch.exp(0.5 * lat[:, 1]) * 0.5
+        ctx.model = model
+        ctx.save_for_backward(x, mq_u8, mp_u8, h1[0], h1[1], h2[0], h2[1], fac)
+        return z[0], mean[0], logvar[0], z[1], mean[1], logvar[1]
+
+    @staticmethod
+    def backward(ctx, dzq, dmq, dlq, dzp, dmp, dlp):
+        model = ctx.model
+        lay = model._lay()
+        x, mq_u8, mp_u8, h1q, h1p, h2q, h2p, fac = ctx.saved_tensors
+        dev, B, Ld = x.device, x.shape[0], lay.L
+        seeds = torch.zeros(2, 2, B, Ld, device=dev)  # [pass][dmean | dlogvar], reparameterisation path folded in
+        for p, (dz, dm, dl) in enumerate(((dzq, dmq, dlq), (dzp, dmp, dlp))):
+            if dm is not None:
+                seeds[p, 0] += dm
+            if dl is not None:
+                seeds[p, 1] += dl
+            if dz is not None:
+                seeds[p, 0] += dz
+                seeds[p, 1].addcmul_(dz, fac[p])
+        part = model._partials(dev, "enc")
+        nb = encoder_bwd(x, model._enc_img(), [mq_u8, mp_u8], [h1q, h1p], [h2q, h2p], [seeds[0, 0], seeds[1, 0]],
+                         [seeds[0, 1], seeds[1, 1]], part, lay.d, lay.L, mask_augm=lay.mask_augm)
+        flat = torch.empty(lay.n_enc, device=dev)
+        _, gidx = lay.device_tables(dev)
+        reduce_partials(part, nb, lay.enc_part, gidx[:lay.n_enc], flat)
+        grads = model._split_flat(flat, 0, 6)
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
 class DecoderFn(torch.autograd.Function):
     """(z, 6 decoder tensors) -> xhat.  Reference: VAE.py:397-401."""
 
@@ -264,13 +315,14 @@ class LossFn(torch.autograd.Function):
         lp_buf = torch.empty(max_blocks, 8, dtype=torch.float64, device=dev)
         nb = loss_fwd_bwd(x, xs, cfg["maskA"], cfg["maskB"], cfg["cA"], cfg["cE"], ms, ls, eps_ml, cfg["bq"], cfg["bp"],
                           cfg["cr"], cfg["wml"], 1.0 / B, cfg["x_logvar"], dx, dm, dl, lp_buf, d, Ld)
-        sums = lp_buf[:nb].sum(0)  # float64 [8]
-        c = HALF_LOG_2PI * B * d
+        # block partials -> [loss | 8 raw sums] in ONE launch (vpc_loss_finalize: doubles inside, fixed order): the torch
+        # expression it replaces was ~15 tiny launches per loss() call - the API path is launch-bound at the reference's
+        # batch sizes
         cA, cE = cfg["cA"], cfg["cE"]
-        loss = cA[0] * (sums[0] + c) + cE[0] * (sums[1] + c) + cfg["bq"] * sums[3]
-        if two:
-            loss = loss + cA[1] * (sums[2] + c) + cfg["bp"] * sums[4] + cfg["cr"] * sums[5] - cfg["wml"] * sums[6]
-        loss = (loss / B).float()
+        out9 = torch.empty(9, device=dev)
+        loss_finalize(lp_buf, nb, cA[0], cE[0], cA[1] if two else 0.0, cfg["bq"], cfg["bp"] if two else 0.0,
+                      cfg["cr"] if two else 0.0, cfg["wml"] if two else 0.0, B, B, d, out9)
+        loss, sums = out9[0], out9[1:]
         ctx.two = two
         if need_grad:
             ctx.save_for_backward(*(dx + dm + dl))
@@ -284,8 +336,7 @@ class LossFn(torch.autograd.Function):
             return (None,) * 9
         t = ctx.saved_tensors
         n = 2 if ctx.two else 1
-        dx, dm, dl = t[:n], t[n:2 * n], t[2 * n:]
-        g = [s * gloss for s in (dx + dm + dl)]
+        g = torch._foreach_mul(list(t), gloss)  # one launch for all seeds (gloss is a device scalar: usually 1)
         if ctx.two:
             dxq, dxp, dmq, dmp, dlq, dlp = g
             return None, None, dxq, dxp, dmq, dlq, dmp, dlp, None
