@@ -53,14 +53,15 @@ def flops_per_sample(d, L, passes=2):
                 encoder_bwd=2 * passes * (2 * enc_f - d * 100))
 
 
-def measured_traffic(B, d, L):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+def measured_traffic(B, d, L, precision="f32"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  PMC counters cannot be read from inside this process, so
     the number is the one measured with `rocprofv3 --pmc` on this same command; None for other shapes."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         if (B, d, L) == (65536, 128, 10):
-            return t["kernels"]["dec8_kernel<8,true>"]["hbm_bytes_corrected"]
+            ks = t["precisions"][precision]
+            return next(v["hbm_bytes_corrected"] for k, v in ks.items() if "dec8" in k)
     except Exception:
         pass
     return None
@@ -251,7 +252,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "vpc::dec8_kernel<8,true> (vpc_decoder_fused)",
                      "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
                      "frac": achieved / PEAK[args.precision],
-                     "traffic": measured_traffic(B, d, Ld) if args.precision == "f32" else None,
+                     "traffic": measured_traffic(B, d, Ld, args.precision),
                      "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},
         "kernels_ms": kern_ms,
         "step_tflops_algorithmic": fl["total"] * B * world / (ms_step * 1e-3) / 1e12,
