@@ -67,6 +67,20 @@ def measured_traffic(B, d, L, precision="f32"):
     return None
 
 
+def measured_step_traffic(B, d, L, precision="f32"):
+    """HBM bytes per STEP: the three MFMA kernels from the committed PMC passes (profiles/r02_traffic.json) plus the
+    algorithmic traffic of the two small launches (reduce_step reads 256 partial blocks = 49 MB and writes < 1 MB; draw_step
+    reads the mask and writes mask_p + eps = 22 MB).  None for shapes / precisions without a PMC pass."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if (B, d, L) != (65536, 128, 10):
+            return None
+        ks = t["precisions"]["bf16x3" if precision == "bf16" else precision]  # bf16 moves the same bytes as bf16x3
+        return sum(v["hbm_bytes_corrected"] for v in ks.values()) + 49_000_000 + 22_000_000
+    except Exception:
+        return None
+
+
 def cpu_baseline(B, d, L, seconds=20.0, threads=None):
     """Reference CPU path (port), fp32: 2 warm-up steps + timed steps, median; then the same with autograd anomaly
     detection ON (the reference's drivers enable it, src/experiment_main/imputation.py:19) as a second row.
@@ -255,6 +269,10 @@ def main():
                      "traffic": measured_traffic(B, d, Ld, args.precision),
                      "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},
         "kernels_ms": kern_ms,
+        "step_hbm": (lambda tb: None if tb is None else {
+            "bytes_per_step": tb, "achieved_TBps": tb / (ms_step * 1e-3) / 1e12, "peak_TBps": HBM_PEAK_TBS,
+            "frac": tb / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
+            "compulsory_bytes_per_step": 768 * B})(measured_step_traffic(B, d, Ld, args.precision)),
         "step_tflops_algorithmic": fl["total"] * B * world / (ms_step * 1e-3) / 1e12,
         "settle_steps": settle,
         "per_step_sync_ms": per_step_sync_ms,

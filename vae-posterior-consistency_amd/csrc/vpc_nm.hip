@@ -10,6 +10,9 @@
 //                  touches HBM (loss :2398-2471 / :2774-2823)
 //   nm_finalize    fixed-order reduction of the per-row statistics and the per-wave dW / db partials
 #include "vpc_abi_internal.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "vpc_device.h"
 #include "../../include/vpc.h"
 
@@ -385,12 +388,23 @@ __global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restri
 // 3 runs two rounds and doubles the time at mid-size batches.
 template <int T, bool REG, bool PF>
 static int launch_variant(const NMLossArgs& a, int* n_blocks, size_t lds, hipStream_t st) {
-    static int occ = 0;  // per variant
+    // occupancy of this variant, per (device, dynamic-LDS size): obs_dim decides the LDS footprint
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, int> cache;
+    int dev = 0, occ = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find({dev, lds});
+        if (it != cache.end()) occ = it->second;
+    }
     if (occ == 0) {
         int o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, nm_loss_kernel<T, REG, PF>, 256, lds) != hipSuccess || o < 1)
             o = 1;
         occ = o;
+        std::lock_guard<std::mutex> g(mu);
+        cache[{dev, lds}] = o;
     }
     const long cap = (long)occ * num_cus();
     if (*n_blocks > cap) *n_blocks = (int)cap;
