@@ -123,6 +123,19 @@ def make_collective(world_size: int, rank: int, device, group=None):
         if coll is not None:
             coll.close()
         return None
+    # self-test against the process group: sum of (rank + 1) patterns through both carriers must agree
+    probe = torch.arange(64, dtype=torch.float32, device=device) * (rank + 1)
+    want = probe.clone()
+    dist.all_reduce(want, op=dist.ReduceOp.SUM, group=group)
+    coll(probe)
+    torch.cuda.synchronize(device)
+    good = torch.tensor([1.0 if torch.equal(probe, want) else 0.0], device=device)
+    dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)
+    if float(good.item()) < 0.5:
+        import sys
+        print(f"[vpc] RCCL self-test failed on rank {rank}; using torch.distributed.all_reduce", file=sys.stderr)
+        coll.close()
+        return None
     return coll
 
 
