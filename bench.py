@@ -263,7 +263,9 @@ def main():
                                f"d={d}, L={Ld}, MCAR mask 0.7, p_missingness=30, Adam lr=1e-3, "
                                f"{args.batches} resident batches rotated",
                    "global_batch": Bg, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "vpc::dec8_kernel<8,true> (vpc_decoder_fused)",
+        "roofline": {"bound": "mfma",
+                     "kernel": ("vpc::dec_kernel<8,true,FUSED,1> (small-batch shape)" if tr.last_blocks[1] > (B + 127) // 128
+                                else "vpc::dec8_kernel<8,true>") + " (vpc_decoder_fused)",
                      "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
                      "frac": achieved / PEAK[args.precision],
                      "traffic": measured_traffic(B, d, Ld, args.precision),

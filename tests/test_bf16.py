@@ -104,9 +104,15 @@ def test_vanilla_step_vs_reference_vectors(prec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("d,B", [(128, 1000), (100, 300), (72, 129), (128, 65536)])
-def test_ragged_and_full_size_vs_f32_path(prec, d, B):
-    """Against the fp32 kernels on the same inputs (themselves checked against the oracle at these shapes)."""
+@pytest.mark.parametrize("d,B,tile", [(128, 1000, "auto"), (100, 300, "auto"), (72, 129, "128"), (128, 65536, "auto"),
+                                      (128, 1000, "128"), (40, 300, "auto"), (64, 20000, "auto"), (16, 100, "128"),
+                                      (128, 8192, "auto")])
+def test_ragged_and_full_size_vs_f32_path(prec, d, B, tile, monkeypatch):
+    """Against the fp32 kernels on the same inputs (themselves checked against the oracle at these shapes), in both
+    workgroup shapes ("auto" = the library's choice: the small-batch shape up to B = 16 384; "128" = the throughput shape
+    forced) and for the narrower models (d <= 64 runs the 4-wave decoder kernel in either shape)."""
+    if tile != "auto":
+        monkeypatch.setenv("VPC_TILE", tile)
     params = O.init_params(d, L, seed=7)
     g = torch.Generator().manual_seed(B + d)
     x = torch.rand(B, d, generator=g).to(DEV)
@@ -149,7 +155,7 @@ def test_training_trajectory_tracks_f32(prec):
 def test_unsupported_shapes_raise():
     params = O.init_params(14, L, seed=1)
     with pytest.raises(vpc.VpcError):
-        vpc.FusedTrainer(make_model(vpc.Reg_VAE, 14, params), precision="bf16")
+        vpc.FusedTrainer(make_model(vpc.Reg_VAE, 14, params), precision="bf16")  # obs_dim % 4 != 0
     with pytest.raises(ValueError):
         vpc.FusedTrainer(make_model(vpc.Reg_VAE, 14, params), precision="fp8")
 

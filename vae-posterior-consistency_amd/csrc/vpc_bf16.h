@@ -121,7 +121,10 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 __device__ __forceinline__ s16x4 ds_tr16(const float* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(const_cast<float*>(p)));
 }
-template <int PREC, int KP>
+// SECOND = false: the image has no rows for the block's second 16-row half (odd number of 16-row tiles: W6 at d <= 16, W5's
+// 7 tiles) - those k-slots are zero instead of whatever lies behind the image (uninitialised LDS may hold NaN patterns,
+// and 0 x NaN is not 0).
+template <int PREC, int KP, bool SECOND = true>
 __device__ __forceinline__ BfOp bf_wfrag_T(const float* W, int mt, int kb, int lane) {
     constexpr int MASK = bf_mask(KP);
     const int q = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
@@ -131,11 +134,12 @@ __device__ __forceinline__ BfOp bf_wfrag_T(const float* W, int mt, int kb, int l
     const float* p1 = W + r1 * KP + 8 * (pi ^ (r1 & MASK)) + e;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     BfOp o;
-    const s16x4 h0 = ds_tr16(p0), h1 = ds_tr16(p1);
+    const s16x4 zz = {0, 0, 0, 0};
+    const s16x4 h0 = ds_tr16(p0), h1 = SECOND ? ds_tr16(p1) : zz;
     const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     o.hi = __builtin_bit_cast(bf16x8, h);
     if (PREC == PREC_BF16X3) {
-        const s16x4 l0 = ds_tr16(p0 + 4), l1 = ds_tr16(p1 + 4);
+        const s16x4 l0 = ds_tr16(p0 + 4), l1 = SECOND ? ds_tr16(p1 + 4) : zz;
         const s16x8 l = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         o.lo = __builtin_bit_cast(bf16x8, l);
     } else {
@@ -143,15 +147,47 @@ __device__ __forceinline__ BfOp bf_wfrag_T(const float* W, int mt, int kb, int l
     }
     return o;
 }
-// out tile mt of  W^T[in][out] * in  where `in` has KB blocks over W's ROW (out-feature) index
-template <int PREC, int KB, int KP, int NKB = KB>
+// out tile mt of  W^T[in][out] * in  where `in` has KB blocks over W's ROW (out-feature) index; ROWT = 16-row tiles the
+// image really has (2 KB, or 2 KB - 1)
+template <int PREC, int KB, int KP, int ROWT = 2 * KB>
 __device__ __forceinline__ f32x4 bf_tile_T(const float* W, int mt, const BfOp (&in)[KB], f32x4 acc, int lane) {
+    constexpr int NKB = KB;
     BfOp a[NKB];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) a[kb] = bf_wfrag_T<PREC, KP>(W, mt, kb, lane);
+    for (int kb = 0; kb < NKB; ++kb)
+        a[kb] = (2 * kb + 1 < ROWT) ? bf_wfrag_T<PREC, KP, true>(W, mt, kb, lane) : bf_wfrag_T<PREC, KP, false>(W, mt, kb, lane);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) acc = bf_mma<PREC>(a[kb], in[kb], acc);
     return acc;
+}
+// ---- NB batch tiles per wave (the 4-wave decoder kernel): one weight fragment feeds NB accumulator chains
+template <int PREC, int KB, int KP, int NB, int NKB = KB>
+__device__ __forceinline__ void bf_tile_fwd_nb(const float* W, int mt, const BfOp (&in)[NB][KB], f32x4 (&acc)[NB], int m,
+                                               int q) {
+    BfOp a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) a[kb] = bf_wfrag<PREC, KP>(W, mt, kb, m, q);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = bf_mma<PREC>(a[kb], in[nb][kb], acc[nb]);
+}
+template <int PREC, int KB, int KP, int NB, int ROWT = 2 * KB>
+__device__ __forceinline__ void bf_tile_T_nb(const float* W, int mt, const BfOp (&in)[NB][KB], f32x4 (&acc)[NB], int lane) {
+    constexpr int NKB = KB;
+    BfOp a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+        a[kb] = (2 * kb + 1 < ROWT) ? bf_wfrag_T<PREC, KP, true>(W, mt, kb, lane) : bf_wfrag_T<PREC, KP, false>(W, mt, kb, lane);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = bf_mma<PREC>(a[kb], in[nb][kb], acc[nb]);
+}
+template <int PREC, int KT, int NB>
+__device__ __forceinline__ void bf_acts_nb(const f32x4 (&in)[NB][KT], BfOp (&out)[NB][(KT + 1) / 2]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bf_acts<PREC, KT>(in[nb], out[nb]);
 }
 #endif  // __HIPCC__
 

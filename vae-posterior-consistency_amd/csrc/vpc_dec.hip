@@ -12,6 +12,7 @@
 //  bp=alpha b', cr=alpha.  ml_reg: cA_q=1, bq=b', wml=(epoch/2800) alpha.  vanilla: one pass, cA=1, bq=b'.)
 // The additive constant 0.5*log(2 pi) per element of every NLL term is added on the host.
 #include "vpc_device.h"
+#include "vpc_bf16.h"
 #include "vpc_abi_internal.h"
 #include "vpc_dec_args.h"
 #include <cstdlib>
@@ -23,7 +24,8 @@ namespace vpc {
 // weight fragment read from LDS feeds two independent MFMA chains, and barriers involve 4 waves only.
 // NB = 1: the small-batch shape (64-row workgroup tiles, the passes spread over blockIdx.y; see tile_shape in
 // vpc_abi_internal.h) - same phases, staging and partial-block layout with a single MFMA chain per weight fragment.
-template <int DT, bool VEC, int MODE, int NB>
+// PREC != PREC_F32 (fused mode): the bf16 engine of vpc_bf16.h, as in dec8_kernel.
+template <int DT, bool VEC, int MODE, int NB, int PREC = PREC_F32>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -33,13 +35,15 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     constexpr int CH = DEC_CH, TILE_ROWS = DEC_WAVES * 16 * NB;  // shadows vpc::TILE_ROWS
     constexpr int NA = (16 * DT > H1P ? 16 * DT : H1P);
     constexpr int I6 = (DT + 3) / 4;  // dW6 out tiles per wave (mt = w + 4i)
-    const DecImg im(DT);
+    constexpr bool BF = PREC != PREC_F32;
+    constexpr int S4K = BF ? 32 : S4;  // row pitch of the W4 image
+    const DecImg im(DT, S4K);
     const float* W4 = lds + im.oW4;
     const float* W5 = lds + im.oW5;
     const float* W6 = lds + im.oW6;
     float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
-    float* red = stB + H1P * CH;   // [DEC_WAVES][8]
+    float* red = BF ? stA : stB + H1P * CH;   // [DEC_WAVES][8] (bf16 image: at the LDS limit, aliases the staging buffer)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * w;
     int sb[4];  // per-lane element offsets of the wgrad staging writes (tile 0); tiles add a compile-time constant
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
         fetch_lat(blockIdx.x, p_lo, Lpre);
         have_pre = true;
     }
-    load_image<24>(lds, a.img, im.total);  // 24 576 floats at DT = 8: one round of loads for 256 threads
+    load_image<25>(lds, a.img, im.total);  // <= 25 600 floats at DT = 8: one round of loads for 256 threads
     __syncthreads();
     VPC_STAMP(0);
 
@@ -214,17 +218,27 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     f32x4 acc[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
+                    if (BF) {
+                        BfOp zb[NB][1];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) zb[nb][0] = bf_pack<PREC>(z[nb][0], zero4());
+                        bf_tile_fwd_nb<PREC, 1, S4K, NB>(W4, mt, zb, acc, cc, qq);
+                    } else
                     tile_fwd_nb<1, S4, NB>(W4, mt, z, acc, cc, qq);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) g1[nb][mt] = relu4(acc[nb]);
                 }
                 launder(cc, qq);
+                BfOp g1b[NB][2];
+                if (BF) bf_acts_nb<PREC, H2T, NB>(g1, g1b);
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = zero4();
+                    if (BF) bf_tile_fwd_nb<PREC, 2, 64, NB>(W5, mt, g1b, acc, cc, qq);
+                    else
                     tile_fwd_nb<H2T, 64, NB, NK2>(W5, mt, g1, acc, cc, qq);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) g2[nb][mt] = relu4(acc[nb]);
@@ -291,6 +305,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     }
                 };
                 fetch(0, xv_cur, ua_cur, ub_cur);
+                BfOp g2b[NB][4];
+                if (BF) {
+                    bf_acts_nb<PREC, H1T, NB>(g2, g2b);
+                    bf_tile_fwd_nb<PREC, 4, 128, NB>(W6, 0, g2b, pre_cur, cc, qq);
+                } else
                 tile_fwd_nb<H1T, 128, NB, NK1>(W6, 0, g2, pre_cur, cc, qq);
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
@@ -302,6 +321,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     uint32_t ua_nxt[NB], ub_nxt[NB];
                     if (mt + 1 < DT) {
                         fetch(mt + 1, xv_nxt, ua_nxt, ub_nxt);
+                        if (BF) bf_tile_fwd_nb<PREC, 4, 128, NB>(W6, mt + 1, g2b, pre_nxt, cc, qq);
+                        else
                         tile_fwd_nb<H1T, 128, NB, NK1>(W6, mt + 1, g2, pre_nxt, cc, qq);
                     }
                     const int f0 = 16 * mt + 4 * q;
@@ -358,6 +379,26 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[ch][t], sb);
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
+                        if (BF) {
+#pragma unroll
+                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                BfOp fa[I6];
+#pragma unroll
+                                for (int i = 0; i < I6; ++i)
+                                    fa[i] = bf_pack<PREC>(stage_frag<CH>(stA, (w + 4 * i) % DT, 2 * sb2, cc, qq),
+                                                          stage_frag<CH>(stA, (w + 4 * i) % DT, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                                for (int nt = 0; nt < H1T; ++nt) {
+                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
+                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                                    for (int i = 0; i < I6; ++i)
+                                        if (w + 4 * i < DT) acc6[i][nt] = bf_mma<PREC>(fa[i], fb, acc6[i][nt]);
+                                }
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -392,12 +433,16 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     VPC_STAMP(4);
                     launder(cc, qq);
                     f32x4 dg2[NB][H1T];
+                    BfOp dpreb[NB][(DT + 1) / 2];
+                    if (BF) bf_acts_nb<PREC, DT, NB>(dpre, dpreb);
 #pragma unroll
                     for (int mt = 0; mt < H1T; ++mt) {
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 acc[NB];
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_DBG(4) ? dpre[nb][mt % DT] : zero4();
+                        if (BF) bf_tile_T_nb<PREC, (DT + 1) / 2, 128, NB, DT>(W6, mt, dpreb, acc, 16 * qq + cc);
+                        else
                         if (!VPC_DBG(4)) tile_T_nb<DT, 128, NB>(W6, mt, dpre, acc, cc, qq);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) dg2[nb][mt] = gate_bits(acc[nb], gm2[nb], mt);
@@ -415,6 +460,24 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[ch][t], sb);
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
+                        if (BF) {
+#pragma unroll
+                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const BfOp fa0 = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
+                                                               stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
+                                const BfOp fa1 = bf_pack<PREC>(stage_frag<CH>(stA, (w + 4) % H1T, 2 * sb2, cc, qq),
+                                                               stage_frag<CH>(stA, (w + 4) % H1T, 2 * sb2 + 1, cc, qq));
+#pragma unroll
+                                for (int nt = 0; nt < H2T; ++nt) {
+                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
+                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+                                    acc5[0][nt] = bf_mma<PREC>(fa0, fb, acc5[0][nt]);
+                                    if (w + 4 < H1T) acc5[1][nt] = bf_mma<PREC>(fa1, fb, acc5[1][nt]);
+                                }
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -445,12 +508,16 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     VPC_STAMP(6);
                     launder(cc, qq);
                     f32x4 dg1[NB][H2T];
+                    BfOp dg2b[NB][4];
+                    if (BF) bf_acts_nb<PREC, H1T, NB>(dg2, dg2b);
 #pragma unroll
                     for (int mt = 0; mt < H2T; ++mt) {
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 acc[NB];
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) acc[nb] = VPC_DBG(4) ? dg2[nb][mt] : zero4();
+                        if (BF) bf_tile_T_nb<PREC, 4, 64, NB, H1T>(W5, mt, dg2b, acc, 16 * qq + cc);
+                        else
                         if (!VPC_DBG(4)) tile_T_nb_k<H1T, 64, NB, NK1>(W5, mt, dg2, acc, cc, qq);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) dg1[nb][mt] = gate_bits(acc[nb], gm1[nb], mt);
@@ -466,6 +533,17 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[ch][t], sb);
                         stage_write_b<CH>(stB, 0, z[ch][0], sb);
                         __syncthreads();
+                        if (BF) {
+#pragma unroll
+                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
+                                const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, 0, 2 * sb2, cc, qq),
+                                                              stage_frag<CH>(stB, 0, 2 * sb2 + 1, cc, qq));
+                                acc4 = bf_mma<PREC>(fa, fb, acc4);
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int s = 0; s < CH / 16; ++s) {
                             const f32x4 fa = stage_frag<CH>(stA, w, s, cc, qq);
@@ -475,6 +553,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                         }
                     }
                     launder(cc, qq);
+                    if (BF) {
+                        BfOp dg1b[NB][2];
+                        bf_acts_nb<PREC, H2T, NB>(dg1, dg1b);
+                        bf_tile_T_nb<PREC, 2, S4K, NB>(W4, 0, dg1b, dzt, 16 * qq + cc);
+                    } else
                     tile_T_nb_k<H2T, S4, NB, NK2>(W4, 0, dg1, dzt, cc, qq);
                 }
             }
@@ -531,11 +614,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #endif
 }
 
-static size_t dec_lds(int DT, int mode) {
-    const DecImg im(DT);
+static size_t dec_lds(int DT, int mode, int prec = 0) {
+    const DecImg im(DT, prec ? 32 : S4);
     if (mode == MODE_FWD) return sizeof(float) * im.total;
     const int na = 16 * DT > H1P ? 16 * DT : H1P;
-    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + DEC_WAVES * LOSS_TERMS);
+    return sizeof(float) * (im.total + na * DEC_CH + H1P * DEC_CH + (prec ? 0 : DEC_WAVES * LOSS_TERMS));
 }
 
 template <typename K>
@@ -543,6 +626,23 @@ static int launch(K kern, const DecArgs& args, const TileShape& ts, size_t lds, 
     if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(ts.grid_x, ts.grid_y), dim3(DEC_THREADS), lds, stream, args);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// bf16 / bf16x3 (fused mode, vector layout): the 4-wave kernel in either shape - every d % 4 == 0 (the 8-wave kernel covers
+// d in (64, 128] in the throughput shape)
+static int dispatch_bf(const DecArgs& a, const TileShape& ts, int prec, hipStream_t s) {
+    const int DT = dt_for(a.d);
+    const size_t lds = dec_lds(DT, MODE_FUSED, prec);
+#define VPC_CASE(T)                                                                                                   \
+    case T:                                                                                                           \
+        if (ts.small)                                                                                                 \
+            return prec == PREC_BF16X3 ? launch(dec_kernel<T, true, MODE_FUSED, 1, PREC_BF16X3>, a, ts, lds, s)        \
+                                       : launch(dec_kernel<T, true, MODE_FUSED, 1, PREC_BF16>, a, ts, lds, s);         \
+        return prec == PREC_BF16X3 ? launch(dec_kernel<T, true, MODE_FUSED, DEC_NB, PREC_BF16X3>, a, ts, lds, s)       \
+                                   : launch(dec_kernel<T, true, MODE_FUSED, DEC_NB, PREC_BF16>, a, ts, lds, s);
+    switch (DT) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+    return VPC_ERR_SHAPE;
 }
 
 template <int MODE>
@@ -609,13 +709,12 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
         return VPC_ERR_ARG;
     if (int e = check_common(B, d, L, npass)) return e;
     if (precision < 0 || precision > 2) return VPC_ERR_ARG;
-    if (precision != 0 && dt_for(d) != 8) return VPC_ERR_SHAPE;  // bf16 variants: the 8-wave kernel, d in (64, 128]
     DecArgs a{};
     a.x = x; a.img = dec_img; a.part = partials; a.loss_part = loss_partials; a.eps_ml = eps_ml;
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
     if (lat_pitch != 16) return VPC_ERR_ARG;  // the fused kernel works on padded [B][16] latent workspaces only
     a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    const TileShape ts = tile_shape(B, npass, precision != 0);
+    const TileShape ts = tile_shape(B, npass);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
@@ -634,7 +733,11 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
     // 4-wave / two-tiles-per-wave kernel of this file instead (same arguments, same partial-block layout; kept for A/B
     // runs and for d <= 64).  Small-batch shape: always the 4-wave kernel with one tile per wave.
     const char* e8 = getenv("VPC_DEC8");
-    if (precision != 0) return dec8_dispatch(a, vec, ts.grid_x, precision, (hipStream_t)stream);
+    if (precision != 0) {
+        if (!vec) return VPC_ERR_SHAPE;  // the bf16 variants cover the vector layout (d % 4 == 0) only
+        if (!ts.small && dt_for(d) == 8) return dec8_dispatch(a, vec, ts.grid_x, precision, (hipStream_t)stream);
+        return dispatch_bf(a, ts, precision, (hipStream_t)stream);
+    }
     if (!ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, 0, (hipStream_t)stream);
     return dispatch<MODE_FUSED>(a, vec, ts, (hipStream_t)stream);
 }

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     VPC_CUT();
-                    if (BF) dg2[0][mt] = gate_bits(bf_tile_T<PREC, (DT + 1) / 2, 128>(W6, mt, dpreb, zero4(), 16 * qq + cc), gm2, mt);
+                    if (BF) dg2[0][mt] = gate_bits(bf_tile_T<PREC, (DT + 1) / 2, 128, DT>(W6, mt, dpreb, zero4(), 16 * qq + cc), gm2, mt);
                     else dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
                 }
                 // ---------------- dW5~ += dg2 * g1^T   (28 tiles; owners below)
@@ -401,9 +401,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
                     VPC_CUT();
-                    // (W5 has 112 rows: the fourth 32-row block reads 16 rows of the W6 image behind it, finite bf16 values
-                    // that meet the exact zeros of dg2's padding tile)
-                    if (BF) dg1[0][mt] = gate_bits(bf_tile_T<PREC, 4, 64>(W5, mt, dg2b, zero4(), 16 * qq + cc), gm1, mt);
+                    if (BF) dg1[0][mt] = gate_bits(bf_tile_T<PREC, 4, 64, H1T>(W5, mt, dg2b, zero4(), 16 * qq + cc), gm1, mt);
                     else dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)

@@ -607,7 +607,7 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
     if (lat_pitch != L && z) return VPC_ERR_ARG;  // z is only produced in the dense [B][L] layout
     EncFwdArgs a{};
     a.x = x; a.img = enc_img; a.B = B; a.d = d; a.L = L; a.npass = npass; a.lp = lat_pitch;
-    const TileShape ts = tile_shape(B, npass, precision != PREC_F32);
+    const TileShape ts = tile_shape(B, npass);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
@@ -624,6 +624,10 @@ extern "C" int vpc_encoder_fwd(const float* x, const float* enc_img, int npass, 
         if (!vec || mask_augm) return VPC_ERR_SHAPE;
 #define VPC_CASE(T)                                                                                                    \
     case T:                                                                                                            \
+        if (ts.small)                                                                                                  \
+            return precision == PREC_BF16X3                                                                            \
+                       ? launch(enc_fwd_kernel<T, true, false, 4, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 4, lds, s)    \
+                       : launch(enc_fwd_kernel<T, true, false, 4, PREC_BF16>, a, ts.grid_x, ts.grid_y, 4, lds, s);     \
         return precision == PREC_BF16X3                                                                                \
                    ? launch(enc_fwd_kernel<T, true, false, 8, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 8, lds, s)        \
                    : launch(enc_fwd_kernel<T, true, false, 8, PREC_BF16>, a, ts.grid_x, ts.grid_y, 8, lds, s);
@@ -656,7 +660,7 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG_ENC")) a.dbg = atoi(e);
 #endif
-    const TileShape ts = tile_shape(B, npass, precision != PREC_F32);
+    const TileShape ts = tile_shape(B, npass);
     a.ntiles = ts.ntiles; a.psplit = ts.small;
     bool vec = (d % 4 == 0) && aligned16(x);
     for (int p = 0; p < npass; ++p) {
@@ -672,6 +676,10 @@ extern "C" int vpc_encoder_bwd(const float* x, const float* enc_img, int npass, 
         if (!vec || mask_augm) return VPC_ERR_SHAPE;
 #define VPC_CASE(T)                                                                                                              \
     case T:                                                                                                                      \
+        if (ts.small)                                                                                                            \
+            return precision == PREC_BF16X3                                                                                      \
+                       ? launch(enc_bwd_kernel<T, true, false, 4, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 4, enc_bwd_lds(T, 4), s) \
+                       : launch(enc_bwd_kernel<T, true, false, 4, PREC_BF16>, a, ts.grid_x, ts.grid_y, 4, enc_bwd_lds(T, 4), s); \
         return precision == PREC_BF16X3                                                                                          \
                    ? launch(enc_bwd_kernel<T, true, false, 8, PREC_BF16X3>, a, ts.grid_x, ts.grid_y, 8, enc_bwd_lds(T, 8), s)    \
                    : launch(enc_bwd_kernel<T, true, false, 8, PREC_BF16>, a, ts.grid_x, ts.grid_y, 8, enc_bwd_lds(T, 8), s);

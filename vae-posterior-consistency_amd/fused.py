@@ -36,7 +36,7 @@ class FusedTrainer:
                  precision="f32", collective=None):
         """precision: "f32" (v_mfma_f32_16x16x4_f32, the parity path), "bf16x3" (split-bf16 products on
         v_mfma_f32_16x16x32_bf16: fp32-class accuracy) or "bf16" (plain bf16 inputs, fp32 accumulation and loss math);
-        the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim in (64, 128], obs_dim % 4 == 0 (csrc/vpc_bf16.h).
+        the bf16 forms exist for Reg_VAE / vanilla_VAE with obs_dim % 4 == 0, both workgroup shapes (csrc/vpc_bf16.h).
         collective: carrier of the per-step bucket under data parallelism (dist.FlatAllReduce = ncclAllReduce on the
         compute stream); None = chosen on the first multi-rank step by dist.make_collective (RCCL when the process group
         is NCCL, torch.distributed.all_reduce otherwise)."""
@@ -68,9 +68,8 @@ class FusedTrainer:
         self.prec = ops.PRECISIONS[precision]
         if self.prec:
             lay = self.lay
-            if lay.mask_augm or lay.d % 4 or not 64 < lay.d <= 128:
-                raise L.VpcError("the bf16 / bf16x3 kernels cover the plain encoder with obs_dim in (64, 128], "
-                                 "obs_dim % 4 == 0")
+            if lay.mask_augm or lay.d % 4:
+                raise L.VpcError("the bf16 / bf16x3 kernels cover the plain encoder with obs_dim % 4 == 0 (<= 128)")
             self.pidx_bf, tmpl, self.enc_img_bf = lay.bf16_tables(self.dev)
             self.img_bf = torch.from_numpy(tmpl).to(self.dev)
             ops.pack_weights_bf16(flat, self.pidx_bf, self.img_bf)
