@@ -180,6 +180,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # CPython's generation-2 garbage collection fires once around step 70 of the timed loop (the ctypes argument arrays of
+    # ~350 launches) and, with torch's millions of live objects, pauses the host for 20-40 ms - longer than the work
+    # queued on the GPU at that point (rocprofv3 trace: one 38 ms gap, nothing else).  Collect here, BEFORE the settle
+    # steps: a collection right in front of the timed region leaves the GPU idle for tens of ms and the first timed steps
+    # then run on ramped-down clocks (a 20-step region read 0.369 instead of 0.340 ms / step).
+    gc.collect()
+    gc.disable()
     # settle: until the dominant kernel's event time is stable (all ranks run the same number of groups)
     settle = 0
     if not args.no_settle:
@@ -206,11 +213,6 @@ def main():
     # Inside the timed region only the dominant kernel is bracketed by HIP events (every 8th step); the other launches
     # are sampled right after the region.
     tr.timers, tr.timer_names = {}, {"decoder_fused"}
-    # CPython's generation-2 garbage collection fires once around step 70 of this loop (the ctypes argument arrays of
-    # ~350 launches) and, with torch's millions of live objects, pauses the host for 20-40 ms - longer than the work
-    # queued on the GPU at that point (rocprofv3 trace: one 38 ms gap, nothing else).  Collect before, not during.
-    gc.collect()
-    gc.disable()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
