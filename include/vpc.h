@@ -14,7 +14,7 @@
  *  - return value: 0 ok, 1 bad argument, 2 unsupported shape (d > 128 or L > 15), 3 HIP runtime error.
  *    No exceptions cross the ABI;
  *  - fp32 tensors are row-major and exactly the reference's shapes: x, xhat [B][d]; mean, logvar, eps, z
- *    [B][L]; masks are one byte per element (0 / non-zero), [B][d];
+ *    [B][L]; masks are one byte per element holding 0 or 1 (the kernels convert them with v_cvt_f32_ubyte), [B][d];
  *  - `npass` = 1 (vanilla_VAE) or 2 (Reg_VAE: pass 0 = q, encoded with `mask`; pass 1 = p, encoded with
  *    `mask_p`); per-pass pointers are passed as HOST arrays of `npass` device pointers;
  *  - h1 [B][112] and h2 [B][64] are padded fp32 workspaces (16-byte aligned) that carry the hidden

@@ -44,9 +44,13 @@ __device__ __forceinline__ uint32_t relu_bits(const f32x4 (&act)[T]) {
         for (int j = 0; j < 4; ++j) b |= (act[t][j] > 0.f ? 1u : 0u) << (4 * t + j);
     return b;
 }
+// (v_bfe_i32 of one bit gives 0 / -1: two VALU per element instead of shift-and, compare, select)
 __device__ __forceinline__ f32x4 gate_bits(f32x4 dy, uint32_t bits, int t) {
-    return f32x4{(bits >> (4 * t)) & 1u ? dy[0] : 0.f, (bits >> (4 * t + 1)) & 1u ? dy[1] : 0.f,
-                 (bits >> (4 * t + 2)) & 1u ? dy[2] : 0.f, (bits >> (4 * t + 3)) & 1u ? dy[3] : 0.f};
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        r[j] = __uint_as_float(__float_as_uint(dy[j]) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 4 * t + j, 1));
+    return r;
 }
 
 // ---- NB batch tiles per wave (decoder kernel, one wave per SIMD): one A fragment feeds NB independent
@@ -295,9 +299,11 @@ __device__ __forceinline__ uint32_t ld_mask_raw(const uint8_t* base, long row, i
     }
     return u;
 }
+// Four mask bytes -> four floats.  The ABI's mask contract is 0 / 1 bytes (include/vpc.h; the Python host normalises
+// whatever it is given), which makes this one v_cvt_f32_ubyteN per element instead of and + compare + select: every VALU
+// instruction in the MFMA kernels costs matrix-pipe time (fp32 MFMA and VALU do not overlap on a SIMD).
 __device__ __forceinline__ f32x4 mask_to_f32(uint32_t u) {
-    return f32x4{(u & 0xffu) ? 1.f : 0.f, (u & 0xff00u) ? 1.f : 0.f, (u & 0xff0000u) ? 1.f : 0.f,
-                 (u & 0xff000000u) ? 1.f : 0.f};
+    return f32x4{(float)(u & 0xffu), (float)((u >> 8) & 0xffu), (float)((u >> 16) & 0xffu), (float)(u >> 24)};
 }
 
 // copy a packed image global -> LDS (16-byte granules; n is a multiple of 4).  U loads are kept in flight per

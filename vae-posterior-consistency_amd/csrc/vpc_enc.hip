@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                 }
             };
             auto mk_fb = [&](int o, const f32x4& xv, uint32_t mb) -> f32x4 {
+                if (!AUG) return xv * mask_to_f32(mb & (fx[o] ? 0xffffffffu : 0u));  // columns past the input width: mask 0
                 const f32x4 m = mask_to_f32(mb);
                 f32x4 v;
 #pragma unroll

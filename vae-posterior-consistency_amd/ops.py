@@ -17,14 +17,21 @@ HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 
 def as_mask_u8(mask: torch.Tensor) -> torch.Tensor:
-    """bool / float / uint8 mask -> contiguous uint8 (non-zero = observed)."""
+    """bool / float / uint8 mask -> contiguous uint8 holding 0 / 1 (non-zero = observed): the kernels convert mask bytes
+    with v_cvt_f32_ubyte, so the ABI contract is 0 / 1 bytes (include/vpc.h).  uint8 input of unknown origin is clamped
+    (one small launch); masks this package produced itself are passed through."""
     if mask.dtype == torch.uint8:
-        m = mask
+        m = mask if getattr(mask, "_vpc_mask01", False) else torch.clamp(mask, max=1)
     elif mask.dtype == torch.bool:
         m = mask.contiguous().view(torch.uint8)
     else:
         m = (mask != 0).view(torch.uint8)
-    return m.contiguous()
+    m = m.contiguous()
+    try:
+        m._vpc_mask01 = True  # plain attribute on the tensor object: survives as long as this object is passed around
+    except Exception:
+        pass
+    return m
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
