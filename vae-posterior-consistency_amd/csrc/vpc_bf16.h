@@ -20,8 +20,10 @@
 //   forward  A fragment (row 16 mt + m, block kb, lane group q): ds_read_b128 (hi) + ds_read_b128 (lo)
 //   dgrad    A fragment of W^T (in feature 16 mt + m, block kb of OUT features, lane group q): the same image read with
 //            ds_read_b64_tr_b16 (hardware transpose of a 4-row x 16-column block of 16-bit elements): 2 reads for hi, 2 for lo
-//   wgrad    contracts over batch rows: both operands come from the fp32 staging buffers of the fp32 kernels, two 16-row
-//            slices per 32-row k-block, converted to bf16 in registers (same permutation on both sides, so any order works)
+//   wgrad    contracts over batch rows: the operands are staged in LDS as bf16, row-major [batch row][feature], by the
+//            owner of the row (one conversion per value - the packed operands of the MFMA chain are written as they are),
+//            and read back transposed with ds_read_b64_tr_b16 (bf_stage_* below); the 4-wave decoder kernel still
+//            converts fp32 staging fragments in registers
 #pragma once
 #include "vpc_device.h"
 
@@ -160,6 +162,73 @@ __device__ __forceinline__ f32x4 bf_tile_T(const float* W, int mt, const BfOp (&
     for (int kb = 0; kb < NKB; ++kb) acc = bf_mma<PREC>(a[kb], in[kb], acc);
     return acc;
 }
+// ---- wgrad operands through LDS.  A wgrad contracts over BATCH rows, so both operands must have rows along the k-slots of
+// a lane, while the registers hold them with rows along the lanes (C/D layout).  The fp32 kernels transpose at write time
+// (scattered ds_write_b32 into feature-major buffers) and the first bf16 build converted those fp32 fragments in every
+// reading wave.  Here every value is converted ONCE, by its owner, and stored row-major [batch row][feature] as bf16 (one
+// ds_write_b64 per tile: the lane's 4 features), hi plane and - split form - lo plane; the readers get their fragments with
+// the hardware transpose ds_read_b64_tr_b16 (block rows = batch rows = k-slots, block columns = the 16 features of a tile),
+// two reads per operand and plane, no VALU.  k-slot j of lane group q in k-block kb is batch row 32 kb + 16 (j >> 2) + 4 q
+// + (j & 3) - for both operands, and for a B operand formed in registers from 16-row slices (bf_pack(slice 2 kb, 2 kb + 1)).
+// Layout.  The unit is the 8-byte chunk (row r, tile t, quad p) = the 4 features 16 t + 4 p .. + 3 of batch row r: one lane of
+// a write, one lane address of a transposed read.  Chunks of 8 consecutive rows x one tile form a 256-byte block (one LDS
+// bank row); inside it the chunk sits at 32 (r & 7) + 8 (p ^ ((r >> 2) & 3)) bytes; blocks are ordered (r >> 3) * FT + t
+// (FT = tiles per row of the buffer).  Banking (MI355X_MICROARCH.md "LDS"): a transposed read is served per 32-lane half =
+// 8 consecutive rows x 4 quads of one tile = exactly one block, all 64 banks once; a ds_write_b64 is served per 16
+// consecutive lanes = 16 rows of one (tile, quad) over 32 banks: rows r & 3 pick the 32-byte group, the quad XOR
+// (r >> 2) & 3 the chunk inside it - 16 different chunks mod 128 bytes.  (Plain row-major rows were 4-way conflicted on
+// the write side: 2 k cycles per wgrad round in the decoder, profiles/r02_notes.md.)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int FT>
+__device__ __forceinline__ int bf_stage_off(int row, int t, int p) {  // dword offset of chunk (row, tile t, quad p)
+    return 64 * ((row >> 3) * FT + t) + 8 * (row & 7) + 2 * (p ^ ((row >> 2) & 3));
+}
+// lane (row = batch row inside the staged rows, q) writes its 4 features 16 t + 4 q .. + 3
+template <int PREC, int FT>
+__device__ __forceinline__ void bf_stage_write(float* hi, float* lo, int row, int t, int q, f32x4 v) {
+    const int off = bf_stage_off<FT>(row, t, q);
+    const u32x2 h = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(hi + off) = h;
+    if (PREC == PREC_BF16X3) {
+        const u32x2 l = {pk_bf16_lo(v[0], v[1], h[0]), pk_bf16_lo(v[2], v[3], h[1])};
+        *reinterpret_cast<u32x2*>(lo + off) = l;
+    }
+}
+// the same from an already packed operand (bf_acts / bf_pack: tiles 2 kb and 2 kb + 1 of the lane's row): no conversion at all.
+// NT = tiles the staged activation has (an odd count leaves the second half of the last operand unwritten).
+template <int PREC, int FT, int NT>
+__device__ __forceinline__ void bf_stage_write_op(float* hi, float* lo, int row, int kb, int q, const BfOp& op) {
+    const u32x4 h = __builtin_bit_cast(u32x4, op.hi);
+    const int o0 = bf_stage_off<FT>(row, 2 * kb, q);  // the next tile is the next block: + 64 dwords
+    *reinterpret_cast<u32x2*>(hi + o0) = u32x2{h[0], h[1]};
+    if (2 * kb + 1 < NT) *reinterpret_cast<u32x2*>(hi + o0 + 64) = u32x2{h[2], h[3]};
+    if (PREC == PREC_BF16X3) {
+        const u32x4 l = __builtin_bit_cast(u32x4, op.lo);
+        *reinterpret_cast<u32x2*>(lo + o0) = u32x2{l[0], l[1]};
+        if (2 * kb + 1 < NT) *reinterpret_cast<u32x2*>(lo + o0 + 64) = u32x2{l[2], l[3]};
+    }
+}
+// fragment (A or B operand) of feature tile t, k-block kb (staged rows 32 kb .. 32 kb + 31)
+template <int PREC, int FT>
+__device__ __forceinline__ BfOp bf_stage_frag(const float* hi, const float* lo, int t, int kb, int lane) {
+    const int g = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 32 * kb + 4 * g + rr;
+    const int off = bf_stage_off<FT>(r0, t, pp);  // row r0 + 16: two 8-row block rows further, same place inside the block
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    BfOp o;
+    const s16x4 h0 = ds_tr16(hi + off), h1 = ds_tr16(hi + off + 128 * FT);
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    o.hi = __builtin_bit_cast(bf16x8, h);
+    if (PREC == PREC_BF16X3) {
+        const s16x4 l0 = ds_tr16(lo + off), l1 = ds_tr16(lo + off + 128 * FT);
+        const s16x8 l = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        o.lo = __builtin_bit_cast(bf16x8, l);
+    } else {
+        o.lo = o.hi;
+    }
+    return o;
+}
+
 // ---- NB batch tiles per wave (the 4-wave decoder kernel): one weight fragment feeds NB accumulator chains
 template <int PREC, int KB, int KP, int NB, int NKB = KB>
 __device__ __forceinline__ void bf_tile_fwd_nb(const float* W, int mt, const BfOp (&in)[NB][KB], f32x4 (&acc)[NB], int m,

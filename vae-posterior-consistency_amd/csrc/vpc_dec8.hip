@@ -95,6 +95,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
     // [8][LOSS_TERMS] for the end-of-kernel loss reduction; with the (4 KB larger) bf16 image the kernel is at the 160 KB
     // LDS limit, so there it aliases the staging buffer (only used after the last staging round)
     float* red = BF ? stA : stB + H1P * CH;
+    // bf16 engine: wgrad operands are staged as bf16, row-major (vpc_bf16.h, bf_stage_*): A rows of 8 tile slots, B rows of 7.
+    // Plain bf16 fits all 128 batch rows in the buffers (ONE staging round per wgrad), the split form 64 rows x (hi, lo).
+    constexpr int ROUNDS = PREC == PREC_BF16 ? 1 : 2, SROWS = TILE_ROWS / ROUNDS, SKB = SROWS / 32;
+    float* sAh = stA;
+    float* sAl = stA + SROWS * 64;
+    float* sBh = stB;
+    float* sBl = stB + SROWS * 56;
+    const int sw16 = 16 * (int)(ROUNDS == 1 ? (threadIdx.x >> 6) : ((threadIdx.x >> 6) & 3));  // first staged row of this wave
     __syncthreads();
     VPC_STAMP(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
@@ -188,13 +196,20 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     if (BF) g2[0][mt] = relu4(bf_tile_fwd<PREC, 2, 64>(W5, mt, g1b, zero4(), cc, qq));
                     else g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
                 }
+                // bf16 engine: from here on the PACKED operands are the currency - they feed the next layer's MFMAs, the dgrad
+                // and the wgrad staging writes (one conversion per value); the fp32 tiles die as soon as they are packed
                 BfOp g2b[4];
-                if (BF) bf_acts<PREC, H1T>(g2[0], g2b);
+                uint32_t gm2_bf = 0;
+                if (BF) {
+                    bf_acts<PREC, H1T>(g2[0], g2b);
+                    gm2_bf = relu_bits<H1T>(g2[0]);
+                }
                 launder(cc, qq);
                 VPC_STAMP(2);
                 VPC_CUT();
                 // ---------------- output tiles: forward, loss terms, d/d pre-activation
                 f32x4 dpre[1][DT];
+                BfOp dpreb[(DT + 1) / 2];
                 float sa = 0.f, se = 0.f;
                 const bool hasB = a.mB[p] != nullptr;
                 const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
@@ -260,18 +275,27 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     // below the loop (next to the first use of dpre), keeping 8 tiles of pre / x / masks live
                     asm volatile("" : "+v"(dpre[0][mt][0]), "+v"(dpre[0][mt][1]), "+v"(dpre[0][mt][2]), "+v"(dpre[0][mt][3]),
                                       "+v"(sa), "+v"(se));
+                    if (BF && ((mt & 1) || mt + 1 == DT))
+                        dpreb[mt >> 1] = bf_pack<PREC>(dpre[0][mt & ~1], (mt & 1) ? dpre[0][mt] : zero4());
                 }
                 VPC_STAMP(3);
                 VPC_CUT();
                 if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
-                const uint32_t gm2 = relu_bits<H1T>(g2[0]);
+                const uint32_t gm2 = BF ? gm2_bf : relu_bits<H1T>(g2[0]);
                 // ---------------- dW6~ += dpre * g2^T   (owner: wave w -> out tile w; all 7 in tiles)
                 VPC_CUT();
                 launder(cc, qq);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
                     if (!ABL(2)) __syncthreads();
-                    if (round_w == r && !ABL(1)) {
+                    if (BF) {
+                        if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
+#pragma unroll
+                            for (int kb = 0; kb < (DT + 1) / 2; ++kb) bf_stage_write_op<PREC, 8, DT>(sAh, sAl, sw16 + cc, kb, qq, dpreb[kb]);
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) bf_stage_write_op<PREC, 7, H1T>(sBh, sBl, sw16 + cc, kb, qq, g2b[kb]);
+                        }
+                    } else if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[0][t], sb);
 #pragma unroll
@@ -279,17 +303,18 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     }
                     if (!ABL(2)) __syncthreads();
                     if (BF) {
-                        if (own6) {
+                        if (own6 && !ABL(4)) {
 #pragma unroll
-                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                            for (int kb = 0; kb < SKB; ++kb) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
+                                const BfOp fa = bf_stage_frag<PREC, 8>(sAh, sAl, w, kb, 16 * qq + cc);
+                                BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, 0, kb, 16 * qq + cc);
 #pragma unroll
-                                for (int nt = 0; nt < H1T; ++nt) {
-                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
-                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+                                for (int nt = 0; nt < H1T; ++nt) {  // two fragments in flight, not seven (registers)
+                                    const BfOp fn = bf_stage_frag<PREC, 7>(sBh, sBl, nt + 1 < H1T ? nt + 1 : nt, kb, 16 * qq + cc);
+                                    __builtin_amdgcn_sched_barrier(0);
                                     acc6[nt] = bf_mma<PREC>(fa, fb, acc6[nt]);
+                                    fb = fn;
                                 }
                             }
                         }
@@ -315,8 +340,6 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg2[1][H1T];
-                BfOp dpreb[(DT + 1) / 2];
-                if (BF) bf_acts<PREC, DT>(dpre[0], dpreb);
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -342,10 +365,22 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 }
                 const uint32_t gm1 = relu_bits<H2T>(g1r[0]);
                 const int nt5 = w & 3, mt5 = 4 * (w >> 2);
+                BfOp dg2b[4], g1rb[2];
+                if (BF) {
+                    bf_acts<PREC, H1T>(dg2[0], dg2b);
+                    bf_acts<PREC, H2T>(g1r[0], g1rb);
+                }
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
                     if (!ABL(2)) __syncthreads();
-                    if (round_w == r && !ABL(1)) {
+                    if (BF) {
+                        if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) bf_stage_write_op<PREC, 8, H1T>(sAh, sAl, sw16 + cc, kb, qq, dg2b[kb]);
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 7, H2T>(sBh, sBl, sw16 + cc, kb, qq, g1rb[kb]);
+                        }
+                    } else if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[0][t], sb);
 #pragma unroll
@@ -355,17 +390,18 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     // owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3; out tile 7 does not exist, so waves 4..7
                     // run three: 7 tiles on every SIMD (waves s and s + 4) instead of 8 / 8 / 8 / 4 with one wave per out tile
                     if (BF) {
+                        if (!ABL(4)) {
 #pragma unroll
-                        for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt5, 2 * sb2, cc, qq),
-                                                          stage_frag<CH>(stB, nt5, 2 * sb2 + 1, cc, qq));
+                            for (int kb = 0; kb < SKB; ++kb) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, nt5, kb, 16 * qq + cc);
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (i < 3 || w < 4) {
-                                    const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt5 + i, 2 * sb2, cc, qq),
-                                                                  stage_frag<CH>(stA, mt5 + i, 2 * sb2 + 1, cc, qq));
-                                    acc5[i] = bf_mma<PREC>(fa, fb, acc5[i]);
+                                for (int i = 0; i < 4; ++i) {
+                                    if (i < 3 || w < 4) {
+                                        const BfOp fa = bf_stage_frag<PREC, 8>(sAh, sAl, mt5 + i, kb, 16 * qq + cc);
+                                        acc5[i] = bf_mma<PREC>(fa, fb, acc5[i]);
+                                    }
+                                    if (PREC == PREC_BF16X3) __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
                         }
@@ -395,8 +431,6 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg1[1][H2T];
-                BfOp dg2b[4];
-                if (BF) bf_acts<PREC, H1T>(dg2[0], dg2b);
 #pragma unroll
                 for (int mt = 0; mt < H2T; ++mt) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -409,23 +443,29 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 fetch_stats();  // the pass-end operands come in under this phase's MFMAs
+                BfOp dg1b[2];
+                if (BF) bf_acts<PREC, H2T>(dg1[0], dg1b);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
                     if (!ABL(2)) __syncthreads();
-                    if (round_w == r && !ABL(1)) {
+                    if (BF) {
+                        if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 8, H2T>(sAh, sAl, sw16 + cc, kb, qq, dg1b[kb]);
+                            bf_stage_write_op<PREC, 7, 1>(sBh, sBl, sw16 + cc, 0, qq, zb[0]);
+                        }
+                    } else if (round_w == r && !ABL(1)) {
 #pragma unroll
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[0][t], sb);
                         stage_write_b<CH>(stB, 0, z[0][0], sb);
                     }
                     if (!ABL(2)) __syncthreads();
                     if (BF) {
-                        if (own4) {
+                        if (own4 && !ABL(4)) {
 #pragma unroll
-                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
-                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
-                                const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, 0, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stB, 0, 2 * sb2 + 1, cc, qq));
+                            for (int kb = 0; kb < SKB; ++kb) {
+                                const BfOp fa = bf_stage_frag<PREC, 8>(sAh, sAl, w, kb, 16 * qq + cc);
+                                const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, 0, kb, 16 * qq + cc);
                                 acc4 = bf_mma<PREC>(fa, fb, acc4);
                             }
                         }
@@ -441,8 +481,6 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 }
                 launder(cc, qq);
                 if (BF) {
-                    BfOp dg1b[2];
-                    bf_acts<PREC, H2T>(dg1[0], dg1b);
                     dzt[0] = bf_tile_T<PREC, 2, S4K>(W4, 0, dg1b, zero4(), 16 * qq + cc);
                 } else {
                     tile_T_nb_k<H2T, S4, 1, NK2>(W4, 0, dg1, dzt, cc, qq);

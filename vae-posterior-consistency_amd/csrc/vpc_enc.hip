@@ -264,6 +264,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
     float* stA = lds + nW;             // [112][CH]  dY operands (dml, dh2, dh1)
     float* stB = stA + H1P * CH;       // [112][CH]  activations (h2, h1)
     float* db1s = stB + H1P * CH;      // [NW][128]: per-wave bias-gradient sums (no atomics across waves: bit-reproducible)
+    // bf16 engine: the same buffers hold the operands as bf16, row-major [batch row][7 tile slots], hi plane + lo plane
+    // (vpc_bf16.h, bf_stage_*): written once by the owner of the row, read back with the transposing LDS read
+    constexpr bool BF = PREC != PREC_F32;
+    constexpr int SKB = CH / 32;
+    float* sAh = stA;
+    float* sAl = stA + 56 * CH;
+    float* sBh = stB;
+    float* sBl = stB + 56 * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int p_lo = a.psplit ? (int)blockIdx.y : 0, p_hi = a.psplit ? p_lo + 1 : a.npass;
     // row-layout operands of one (tile, pass) through range-checked buffer descriptors: rows past B read 0 - zero seeds make
@@ -371,20 +379,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             // ---- dh2 = relu'(h2) * (W3~^T dml)
             launder(cc, qq);
             f32x4 dh2[H2T];
+            BfOp dmlb[1], dh2b[2];  // bf16 engine: packed once, used by the dgrad MFMAs AND the wgrad staging writes
+            if (BF) dmlb[0] = bf_pack<PREC>(dml[0], dml[1]);
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) {
-                if (PREC == PREC_F32) {
-                    dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
-                } else {
-                    BfOp dmlb[1] = {bf_pack<PREC>(dml[0], dml[1])};
-                    dh2[mt] = gate4(bf_tile_T<PREC, 1, 64>(W3, mt, dmlb, zero4(), 16 * qq + cc), h2[mt]);
-                }
+                if (PREC == PREC_F32) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
+                else dh2[mt] = gate4(bf_tile_T<PREC, 1, 64>(W3, mt, dmlb, zero4(), 16 * qq + cc), h2[mt]);
             }
+            if (BF) bf_acts<PREC, H2T>(dh2, dh2b);
             VPC_STAMP(2);
             // ---- dW2~ += dh2 * h1^T   (owner: wave w -> in tiles w + NW o < 7, all 4 out tiles)
             launder(cc, qq);
             if (!ABLE(2)) __syncthreads();
-            if (!ABLE(1)) {
+            if (BF && !ABLE(1)) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 7, H2T>(sAh, sAl, 16 * w + cc, kb, qq, dh2b[kb]);
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h1[t]);
+            } else if (!ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dh2[t], sb);
 #pragma unroll
@@ -394,16 +406,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
                 if (PREC != PREC_F32) {
-                    if (w + NW * o < H1T) {
+                    if (w + NW * o < H1T && !ABLE(4)) {
 #pragma unroll
-                        for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                        for (int kb = 0; kb < SKB; ++kb) {
                             asm volatile("" ::: "memory");
-                            const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, w + NW * o, 2 * sb2, cc, qq),
-                                                          stage_frag<CH>(stB, w + NW * o, 2 * sb2 + 1, cc, qq));
+                            const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, w + NW * o, kb, 16 * qq + cc);
 #pragma unroll
                             for (int mt = 0; mt < H2T; ++mt) {
-                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stA, mt, 2 * sb2 + 1, cc, qq));
+                                const BfOp fa = bf_stage_frag<PREC, 7>(sAh, sAl, mt, kb, 16 * qq + cc);
                                 acc2[o][mt] = bf_mma<PREC>(fa, fb, acc2[o][mt]);
                             }
                         }
@@ -447,8 +457,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                 if (PREC == PREC_F32) {
                     dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
                 } else {
-                    BfOp dh2b[2];
-                    bf_acts<PREC, H2T>(dh2, dh2b);
                     dh1[mt] = gate4(bf_tile_T<PREC, 2, 128>(W2, mt, dh2b, zero4(), 16 * qq + cc), h1[mt]);
                 }
                 // db1: per-lane running sums over all tile-passes; the cross-lane reduction happens ONCE, after the
@@ -460,7 +468,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w -> in tiles w + NW o < DT, all 7 out tiles; B straight from global)
             launder(cc, qq);
             if (!ABLE(2)) __syncthreads();
-            if (!ABLE(1)) {
+            if (BF && !ABLE(1)) {
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sAh, sAl, 16 * w + cc, t, qq, dh1[t]);
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h2[t]);
+                bf_stage_write_op<PREC, 7, 6>(sBh, sBl, 16 * w + cc, H2T / 2, qq, dmlb[0]);  // tiles 4, 5
+            } else if (!ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dh1[t], sb);
                 // operands of dW3~ (tile t8 = w + NW o -> out tile t8 >> 2, in tile t8 & 3): h2 -> stB tiles 0..3, dml -> stB tiles 4, 5
@@ -483,11 +497,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                     }
                 } else {
 #pragma unroll
-                    for (int sb2 = 0; sb2 < NS / 2; ++sb2) {
-                        const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stB, H2T + (t8 >> 2), 2 * sb2, cc, qq),
-                                                      stage_frag<CH>(stB, H2T + (t8 >> 2), 2 * sb2 + 1, cc, qq));
-                        const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, t8 & 3, 2 * sb2, cc, qq),
-                                                      stage_frag<CH>(stB, t8 & 3, 2 * sb2 + 1, cc, qq));
+                    for (int kb = 0; kb < SKB; ++kb) {
+                        const BfOp fa = bf_stage_frag<PREC, 7>(sBh, sBl, H2T + (t8 >> 2), kb, 16 * qq + cc);
+                        const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, t8 & 3, kb, 16 * qq + cc);
                         acc3[o] = bf_mma<PREC>(fa, fb, acc3[o]);
                     }
                 }
@@ -509,8 +521,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                             if (2 * sb2 + 5 < NS) ld_xb(o, 2 * sb2 + 5, xq[(2 * sb2 + 1) & 3], mq[(2 * sb2 + 1) & 3]);
 #pragma unroll
                             for (int mt = 0; mt < H1T; ++mt) {
-                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, mt, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stA, mt, 2 * sb2 + 1, cc, qq));
+                                const BfOp fa = bf_stage_frag<PREC, 7>(sAh, sAl, mt, sb2, 16 * qq + cc);
                                 acc1[o][mt] = bf_mma<PREC>(fa, fb, acc1[o][mt]);
                             }
                         }
