@@ -210,7 +210,9 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 // ---------------- output tiles: forward, loss terms, d/d pre-activation
                 f32x4 dpre[1][DT];
                 BfOp dpreb[(DT + 1) / 2];
-                float sa = 0.f, se = 0.f;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                constexpr float NLOG2E = -1.4426950408889634f;
+                f32x2 sa2 = {0.f, 0.f}, se2 = {0.f, 0.f};
                 const bool hasB = a.mB[p] != nullptr;
                 const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
                 // x / mask words of tile mt + 1 are requested before tile mt's MFMAs and consumed after the next tile's: a
@@ -261,25 +263,33 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     const f32x4 mE = mA * (1.f - mask_to_f32(ub));
                     // every VALU instruction here costs MFMA time (fp32 MFMA and VALU do not overlap on a SIMD, see
                     // tools/microbench/mfma_valu_overlap.hip): constants are folded per pass, not per element
+                    // two elements per instruction (v_pk_mul / v_pk_fma / v_pk_add_f32) wherever the math is not transcendental
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xh = fast_sigmoid(pre[0][j]);
-                        const float diff = xh - xv[j];
-                        const float t = __builtin_fmaf(diff * diff, hinv_s2, half_lv);
-                        sa = __builtin_fmaf(mA[j], t, sa);
-                        se = __builtin_fmaf(mE[j], t, se);
-                        const float wgt = __builtin_fmaf(kE, mE[j], kA * mA[j]);  // (cA mA + cE mE) / (sigma^2 B)
-                        dpre[0][mt][j] = (wgt * diff) * __builtin_fmaf(-xh, xh, xh);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 p2 = {pre[0][2 * h], pre[0][2 * h + 1]}, x2 = {xv[2 * h], xv[2 * h + 1]};
+                        const f32x2 a2 = {mA[2 * h], mA[2 * h + 1]}, e2 = {mE[2 * h], mE[2 * h + 1]};
+                        const f32x2 en = p2 * NLOG2E;
+                        const f32x2 den = f32x2{__builtin_amdgcn_exp2f(en[0]), __builtin_amdgcn_exp2f(en[1])} + 1.f;
+                        const f32x2 xh = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                        const f32x2 diff = xh - x2;
+                        const f32x2 t = __builtin_elementwise_fma(diff * diff, f32x2{hinv_s2, hinv_s2}, f32x2{half_lv, half_lv});
+                        sa2 = __builtin_elementwise_fma(a2, t, sa2);
+                        se2 = __builtin_elementwise_fma(e2, t, se2);
+                        const f32x2 wgt = __builtin_elementwise_fma(f32x2{kE, kE}, e2, a2 * kA);  // (cA mA + cE mE) / (sigma^2 B)
+                        const f32x2 dp = (wgt * diff) * __builtin_elementwise_fma(-xh, xh, xh);
+                        dpre[0][mt][2 * h] = dp[0];
+                        dpre[0][mt][2 * h + 1] = dp[1];
                     }
                     // pin this tile's VALU here: without a volatile use hipcc sinks the sigmoid / loss code of ALL tiles
                     // below the loop (next to the first use of dpre), keeping 8 tiles of pre / x / masks live
                     asm volatile("" : "+v"(dpre[0][mt][0]), "+v"(dpre[0][mt][1]), "+v"(dpre[0][mt][2]), "+v"(dpre[0][mt][3]),
-                                      "+v"(sa), "+v"(se));
+                                      "+v"(sa2), "+v"(se2));
                     if (BF && ((mt & 1) || mt + 1 == DT))
                         dpreb[mt >> 1] = bf_pack<PREC>(dpre[0][mt & ~1], (mt & 1) ? dpre[0][mt] : zero4());
                 }
                 VPC_STAMP(3);
                 VPC_CUT();
+                const float sa = sa2[0] + sa2[1], se = se2[0] + se2[1];
                 if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
                 const uint32_t gm2 = BF ? gm2_bf : relu_bits<H1T>(g2[0]);
                 // ---------------- dW6~ += dpre * g2^T   (owner: wave w -> out tile w; all 7 in tiles)
