@@ -162,6 +162,66 @@ __device__ __forceinline__ f32x4 bf_tile_T(const float* W, int mt, const BfOp (&
     for (int kb = 0; kb < NKB; ++kb) acc = bf_mma<PREC>(a[kb], in[kb], acc);
     return acc;
 }
+// ---- a dgrad layer with the fragments of tile mt + 1 requested before the MFMAs of tile mt.  With the 16-cycle bf16 MFMAs a
+// tile's chain (KB MFMAs) is shorter than the LDS round trip of its fragments: tile by tile, each wave waits ~150 cycles per
+// ~64 cycles of MFMA issue (profiles/r02_notes.md, "dg2" / "dg1" stamps).  PF = fragments (k-blocks) of the next tile kept
+// in flight: all KB in the plain form (hi only), fewer in the split form (registers).
+template <int PREC, int KB, int KP, int NT, int ROWT, int PF, typename F>
+__device__ __forceinline__ void bf_layer_T(const float* W, const BfOp (&in)[KB], int lane, F&& sink) {
+    static_assert(PF >= 1 && PF <= KB, "");
+    auto frag = [&](int mt, int kb) {
+        return (2 * kb + 1 < ROWT) ? bf_wfrag_T<PREC, KP, true>(W, mt, kb, lane) : bf_wfrag_T<PREC, KP, false>(W, mt, kb, lane);
+    };
+    BfOp cur[PF];
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb) cur[kb] = frag(0, kb);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        BfOp rest[KB - PF + 1];  // (+1: no zero-length array)
+#pragma unroll
+        for (int kb = PF; kb < KB; ++kb) rest[kb - PF] = frag(mt, kb);
+        BfOp nxt[PF];
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) nxt[kb] = frag(mt + 1 < NT ? mt + 1 : mt, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) acc = bf_mma<PREC>(cur[kb], in[kb], acc);
+#pragma unroll
+        for (int kb = PF; kb < KB; ++kb) acc = bf_mma<PREC>(rest[kb - PF], in[kb], acc);
+        sink(mt, acc);
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) cur[kb] = nxt[kb];
+    }
+}
+
+// the same for a forward layer (row fragments, ds_read_b128)
+template <int PREC, int KB, int KP, int NT, int PF, typename F>
+__device__ __forceinline__ void bf_layer_fwd(const float* W, const BfOp (&in)[KB], int m, int q, F&& sink) {
+    static_assert(PF >= 1 && PF <= KB, "");
+    BfOp cur[PF];
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb) cur[kb] = bf_wfrag<PREC, KP>(W, 0, kb, m, q);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        BfOp rest[KB - PF + 1];
+#pragma unroll
+        for (int kb = PF; kb < KB; ++kb) rest[kb - PF] = bf_wfrag<PREC, KP>(W, mt, kb, m, q);
+        BfOp nxt[PF];
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) nxt[kb] = bf_wfrag<PREC, KP>(W, mt + 1 < NT ? mt + 1 : mt, kb, m, q);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) acc = bf_mma<PREC>(cur[kb], in[kb], acc);
+#pragma unroll
+        for (int kb = PF; kb < KB; ++kb) acc = bf_mma<PREC>(rest[kb - PF], in[kb], acc);
+        sink(mt, acc);
+#pragma unroll
+        for (int kb = 0; kb < PF; ++kb) cur[kb] = nxt[kb];
+    }
+}
+
 // ---- wgrad operands through LDS.  A wgrad contracts over BATCH rows, so both operands must have rows along the k-slots of
 // a lane, while the registers hold them with rows along the lanes (C/D layout).  The fp32 kernels transpose at write time
 // (scattered ds_write_b32 into feature-major buffers) and the first bf16 build converted those fp32 fragments in every

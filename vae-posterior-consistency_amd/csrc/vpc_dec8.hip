@@ -190,11 +190,15 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
                 BfOp g1b[2];
                 if (BF) bf_acts<PREC, H2T>(g1[0], g1b);
+                if (BF) {
+                    bf_layer_fwd<PREC, 2, 64, H1T, PREC == PREC_BF16 ? 2 : 1>(W5, g1b, cc, qq,
+                                                                         [&](int mt, f32x4 acc) { g2[0][mt] = relu4(acc); });
+                } else {
 #pragma unroll
-                for (int mt = 0; mt < H1T; ++mt) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (BF) g2[0][mt] = relu4(bf_tile_fwd<PREC, 2, 64>(W5, mt, g1b, zero4(), cc, qq));
-                    else g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
+                    for (int mt = 0; mt < H1T; ++mt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        g2[0][mt] = relu4(tile_fwd_p2<H2T, 64, NK2>(W5, mt, g1[0], cc, qq));
+                    }
                 }
                 // bf16 engine: from here on the PACKED operands are the currency - they feed the next layer's MFMAs, the dgrad
                 // and the wgrad staging writes (one conversion per value); the fp32 tiles die as soon as they are packed
@@ -244,6 +248,14 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 f32x4 xv_n;
                 uint32_t ua_n, ub_n;
                 fetch(0, xv_n, ua_n, ub_n);
+                // plain bf16: the W6 fragments of tile mt + 1 are requested before tile mt's MFMAs and loss math (4 MFMAs of 16
+                // cycles do not cover an LDS round trip; in the split form the 12-MFMA chain nearly does, and registers are short)
+                constexpr bool WPF = PREC == PREC_BF16;
+                BfOp w6n[4];
+                if (WPF) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) w6n[kb] = bf_wfrag<PREC, 128>(W6, 0, kb, cc, qq);
+                }
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
                     VPC_CUT();
@@ -251,7 +263,19 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                     uint32_t ua = ua_n, ub = ub_n;
                     if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
                     f32x4 pre[1];
-                    if (BF) pre[0] = bf_tile_fwd<PREC, 4, 128>(W6, mt, g2b, zero4(), cc, qq);
+                    if (WPF) {
+                        BfOp w6c[4];
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) w6c[kb] = w6n[kb];
+                        if (mt + 1 < DT) {
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) w6n[kb] = bf_wfrag<PREC, 128>(W6, mt + 1, kb, cc, qq);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        pre[0] = zero4();
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) pre[0] = bf_mma<PREC>(w6c[kb], g2b[kb], pre[0]);
+                    } else if (BF) pre[0] = bf_tile_fwd<PREC, 4, 128>(W6, mt, g2b, zero4(), cc, qq);
                     else pre[0] = tile_fwd_p2<H1T, 128, NK1>(W6, mt, g2[0], cc, qq);
                     if (VEC && mt >= DT / 2) {
                         const uint32_t vm = opaque_mask(16 * mt + 4 * q + 3 < a.d);
@@ -350,12 +374,16 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg2[1][H1T];
+                if (BF) {
+                    bf_layer_T<PREC, (DT + 1) / 2, 128, H1T, DT, PREC == PREC_BF16 ? (DT + 1) / 2 : 1>(
+                        W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) { dg2[0][mt] = gate_bits(acc, gm2, mt); });
+                } else {
 #pragma unroll
-                for (int mt = 0; mt < H1T; ++mt) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    VPC_CUT();
-                    if (BF) dg2[0][mt] = gate_bits(bf_tile_T<PREC, (DT + 1) / 2, 128, DT>(W6, mt, dpreb, zero4(), 16 * qq + cc), gm2, mt);
-                    else dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
+                    for (int mt = 0; mt < H1T; ++mt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        VPC_CUT();
+                        dg2[0][mt] = gate_bits(tile_T_p2<DT, 128>(W6, mt, dpre[0], cc, qq), gm2, mt);
+                    }
                 }
                 // ---------------- dW5~ += dg2 * g1^T   (28 tiles; owners below)
                 VPC_STAMP(5);
@@ -441,12 +469,16 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 VPC_CUT();
                 launder(cc, qq);
                 f32x4 dg1[1][H2T];
+                if (BF) {
+                    bf_layer_T<PREC, 4, 64, H2T, H1T, PREC == PREC_BF16 ? 4 : 1>(
+                        W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) { dg1[0][mt] = gate_bits(acc, gm1, mt); });
+                } else {
 #pragma unroll
-                for (int mt = 0; mt < H2T; ++mt) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    VPC_CUT();
-                    if (BF) dg1[0][mt] = gate_bits(bf_tile_T<PREC, 4, 64, H1T>(W5, mt, dg2b, zero4(), 16 * qq + cc), gm1, mt);
-                    else dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
+                    for (int mt = 0; mt < H2T; ++mt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        VPC_CUT();
+                        dg1[0][mt] = gate_bits(tile_T_p2<H1T, 64, NK1>(W5, mt, dg2[0], cc, qq), gm1, mt);
+                    }
                 }
                 // ---------------- dW4~ += dg1 * z^T   (owner: wave w < 4 -> out tile w)
                 VPC_STAMP(7);

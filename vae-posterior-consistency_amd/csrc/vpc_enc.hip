@@ -169,22 +169,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFw
                 constexpr int KB1 = (DT + 1) / 2;
                 BfOp xb[KB1];
                 bf_acts<PREC, DT>(xin, xb);
-#pragma unroll
-                for (int mt = 0; mt < H1T; ++mt) {
-                    f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q);
-                    acc = bf_tile_fwd<PREC, KB1, S1>(W1, mt, xb, acc, cc, qq);
-                    h1[mt] = relu4(acc);
+                // (fragments of tile mt + 1 in flight during tile mt: vpc_bf16.h, bf_layer_fwd)
+                bf_layer_fwd<PREC, KB1, S1, H1T, PREC == PREC_BF16 ? KB1 : 1>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
+                    h1[mt] = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
                     st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
-                }
+                });
                 VPC_STAMP(2);
                 launder(cc, qq);
                 BfOp h1b[4];
                 bf_acts<PREC, H1T>(h1, h1b);
-#pragma unroll
-                for (int mt = 0; mt < H2T; ++mt) {
-                    h2[mt] = relu4(bf_tile_fwd<PREC, 4, 128>(W2, mt, h1b, zero4(), cc, qq));
+                bf_layer_fwd<PREC, 4, 128, H2T, PREC == PREC_BF16 ? 4 : 1>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
+                    h2[mt] = relu4(acc);
                     st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
-                }
+                });
                 VPC_STAMP(3);
                 BfOp h2b[2];
                 bf_acts<PREC, H2T>(h2, h2b);
@@ -452,17 +449,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             // ---- dh1 = relu'(h1) * (W2~^T dh2);  db1 += dh1
             launder(cc, qq);
             f32x4 dh1[H1T];
+            // db1: per-lane running sums over all tile-passes; the cross-lane reduction happens ONCE, after the
+            // loops (it used to be 4 DPP adds + a predicated ds_add per value and pass: ~170 VALU and 28 exec-masked
+            // basic blocks in the middle of the dgrad MFMA stream)
+            if (BF) {
+                bf_layer_T<PREC, 2, 128, H1T, 4, PREC == PREC_BF16 ? 2 : 1>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                    dh1[mt] = gate4(acc, h1[mt]);
+                    dbacc[mt] += dh1[mt];
+                });
+            } else {
 #pragma unroll
-            for (int mt = 0; mt < H1T; ++mt) {
-                if (PREC == PREC_F32) {
+                for (int mt = 0; mt < H1T; ++mt) {
                     dh1[mt] = gate4(tile_T<H2T, 128, NK2>(W2, mt, dh2, zero4(), cc, qq), h1[mt]);
-                } else {
-                    dh1[mt] = gate4(bf_tile_T<PREC, 2, 128>(W2, mt, dh2b, zero4(), 16 * qq + cc), h1[mt]);
+                    dbacc[mt] += dh1[mt];
                 }
-                // db1: per-lane running sums over all tile-passes; the cross-lane reduction happens ONCE, after the
-                // loops (it used to be 4 DPP adds + a predicated ds_add per value and pass: ~170 VALU and 28 exec-masked
-                // basic blocks in the middle of the dgrad MFMA stream)
-                dbacc[mt] += dh1[mt];
             }
             VPC_STAMP(4);
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w -> in tiles w + NW o < DT, all 7 out tiles; B straight from global)
