@@ -191,7 +191,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 BfOp g1b[2];
                 if (BF) bf_acts<PREC, H2T>(g1[0], g1b);
                 if (BF) {
-                    bf_layer_fwd<PREC, 2, 64, H1T, PREC == PREC_BF16 ? 2 : 1>(W5, g1b, cc, qq,
+                    bf_layer_fwd<PREC, 2, 64, H1T, 2>(W5, g1b, cc, qq,
                                                                          [&](int mt, f32x4 acc) { g2[0][mt] = relu4(acc); });
                 } else {
 #pragma unroll
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
                 f32x4 dg2[1][H1T];
                 if (BF) {
-                    bf_layer_T<PREC, (DT + 1) / 2, 128, H1T, DT, PREC == PREC_BF16 ? (DT + 1) / 2 : 1>(
+                    bf_layer_T<PREC, (DT + 1) / 2, 128, H1T, DT, PREC == PREC_BF16 ? (DT + 1) / 2 : 2>(
                         W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) { dg2[0][mt] = gate_bits(acc, gm2, mt); });
                 } else {
 #pragma unroll
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
                 f32x4 dg1[1][H2T];
                 if (BF) {
-                    bf_layer_T<PREC, 4, 64, H2T, H1T, PREC == PREC_BF16 ? 4 : 1>(
+                    bf_layer_T<PREC, 4, 64, H2T, H1T, PREC == PREC_BF16 ? 4 : 2>(
                         W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) { dg1[0][mt] = gate_bits(acc, gm1, mt); });
                 } else {
 #pragma unroll

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFw
                 BfOp xb[KB1];
                 bf_acts<PREC, DT>(xin, xb);
                 // (fragments of tile mt + 1 in flight during tile mt: vpc_bf16.h, bf_layer_fwd)
-                bf_layer_fwd<PREC, KB1, S1, H1T, PREC == PREC_BF16 ? KB1 : 1>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
+                bf_layer_fwd<PREC, KB1, S1, H1T, PREC == PREC_BF16 ? KB1 : (KB1 < 2 ? KB1 : 2)>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
                     h1[mt] = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
                     st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
                 });
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFw
                 launder(cc, qq);
                 BfOp h1b[4];
                 bf_acts<PREC, H1T>(h1, h1b);
-                bf_layer_fwd<PREC, 4, 128, H2T, PREC == PREC_BF16 ? 4 : 1>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
+                bf_layer_fwd<PREC, 4, 128, H2T, PREC == PREC_BF16 ? 4 : 2>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
                     h2[mt] = relu4(acc);
                     st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
                 });
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             // loops (it used to be 4 DPP adds + a predicated ds_add per value and pass: ~170 VALU and 28 exec-masked
             // basic blocks in the middle of the dgrad MFMA stream)
             if (BF) {
-                bf_layer_T<PREC, 2, 128, H1T, 4, PREC == PREC_BF16 ? 2 : 1>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                bf_layer_T<PREC, 2, 128, H1T, 4, 2>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
                     dh1[mt] = gate4(acc, h1[mt]);
                     dbacc[mt] += dh1[mt];
                 });
