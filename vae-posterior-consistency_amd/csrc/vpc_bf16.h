@@ -84,6 +84,13 @@ __device__ __forceinline__ f32x4 bf_mma(const BfOp& a, const BfOp& b, f32x4 acc)
     return VPC_MFMA_BF(a.hi, b.hi, acc);
 }
 
+// ReLU backward from a PACKED activation operand: element j of tile `second` (0: tile 2 kb, 1: tile 2 kb + 1) passes where the
+// stored bf16 is not zero (a relu output is >= +0, and bf16 rounding keeps a positive normal positive)
+__device__ __forceinline__ f32x4 bf_gate(f32x4 dy, const BfOp& act, int second) {
+    const u32x4 h = __builtin_bit_cast(u32x4, act.hi);
+    const uint32_t w0 = second ? h[2] : h[0], w1 = second ? h[3] : h[1];
+    return f32x4{(w0 & 0xffffu) ? dy[0] : 0.f, (w0 >> 16) ? dy[1] : 0.f, (w1 & 0xffffu) ? dy[2] : 0.f, (w1 >> 16) ? dy[3] : 0.f};
+}
 // activations of a layer as MFMA B operands: KT fp32 tiles -> (KT + 1) / 2 blocks of 32 features
 template <int PREC, int KT>
 __device__ __forceinline__ void bf_acts(const f32x4 (&in)[KT], BfOp (&out)[(KT + 1) / 2]) {

@@ -170,21 +170,35 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_fwd_kernel(EncFw
                 BfOp xb[KB1];
                 bf_acts<PREC, DT>(xin, xb);
                 // (fragments of tile mt + 1 in flight during tile mt: vpc_bf16.h, bf_layer_fwd)
+                // plain bf16: the h1 / h2 workspaces hold the PACKED operands (what the backward kernel's MFMAs consume
+                // anyway): rows of [k-block][q][8 x bf16], 256 / 128 bytes per row inside the same allocation - half the
+                // bytes of the fp32 rows in both directions (enc_fwd is HBM-bound in this form)
+                constexpr bool HPK = PREC == PREC_BF16;
                 bf_layer_fwd<PREC, KB1, S1, H1T, PREC == PREC_BF16 ? KB1 : (KB1 < 2 ? KB1 : 2)>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
                     h1[mt] = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
-                    st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
+                    if (!HPK) st_rows(rh1, lrow, H1P, 16 * mt + 4 * q, h1[mt]);
                 });
                 VPC_STAMP(2);
                 launder(cc, qq);
                 BfOp h1b[4];
                 bf_acts<PREC, H1T>(h1, h1b);
+                if (HPK) {
+                    const __amdgpu_buffer_rsrc_t rp = rows_rsrc(a.h1[p], row0, a.B, 64);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) st_rows(rp, lrow, 64, 16 * kb + 4 * q, __builtin_bit_cast(f32x4, h1b[kb].hi));
+                }
                 bf_layer_fwd<PREC, 4, 128, H2T, PREC == PREC_BF16 ? 4 : 2>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
                     h2[mt] = relu4(acc);
-                    st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
+                    if (!HPK) st_rows(rh2, lrow, H2P, 16 * mt + 4 * q, h2[mt]);
                 });
                 VPC_STAMP(3);
                 BfOp h2b[2];
                 bf_acts<PREC, H2T>(h2, h2b);
+                if (HPK) {
+                    const __amdgpu_buffer_rsrc_t rp = rows_rsrc(a.h2[p], row0, a.B, 32);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) st_rows(rp, lrow, 32, 16 * kb + 4 * q, __builtin_bit_cast(f32x4, h2b[kb].hi));
+                }
                 mu = bf_tile_fwd<PREC, 2, 64>(W3, 0, h2b, zero4(), cc, qq);
                 lv = bf_tile_fwd<PREC, 2, 64>(W3, 1, h2b, zero4(), cc, qq);
             }
@@ -275,7 +289,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
     // dh2, dh1 and every wgrad contribution of such a row exactly zero.  (hipcc turns `ok ? load : 0` into an exec-masked
     // branch with a vmcnt(0) wait at the join.)  The first (tile, pass) of the workgroup is requested before the weight
     // image: in the small-batch shape there is only one, and the two latencies otherwise add up.
-    struct RowIn { f32x4 dml[2], h2[H2T], h1[H1T]; };
+    // plain bf16: h1 / h2 arrive as the packed operands enc_fwd stored (4 + 2 k-blocks of 8 bf16 per lane)
+    constexpr bool HPK = PREC == PREC_BF16;
+    struct RowIn { f32x4 dml[2], h2[HPK ? 1 : H2T], h1[HPK ? 1 : H1T]; BfOp h2p[HPK ? 2 : 1], h1p[HPK ? 4 : 1]; };
     auto fetch_rows = [&](int tile, int p, RowIn& R) {
         const long row0 = (long)tile * TILE_ROWS;
         const int lrow = w * 16 + c;
@@ -286,6 +302,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             const long row = row0 + lrow;
             R.dml[0] = ld_tile<false>(a.dmean[p], row, a.L, 4 * q, a.L, row < a.B);
             R.dml[1] = ld_tile<false>(a.dlogvar[p], row, a.L, 4 * q, a.L, row < a.B);
+        }
+        if (HPK) {
+            const __amdgpu_buffer_rsrc_t rp2 = rows_rsrc(a.h2[p], row0, a.B, 32), rp1 = rows_rsrc(a.h1[p], row0, a.B, 64);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                R.h2p[kb].hi = __builtin_bit_cast(bf16x8, ld_rows(rp2, lrow, 32, 16 * kb + 4 * q));
+                R.h2p[kb].lo = R.h2p[kb].hi;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                R.h1p[kb].hi = __builtin_bit_cast(bf16x8, ld_rows(rp1, lrow, 64, 16 * kb + 4 * q));
+                R.h1p[kb].lo = R.h1p[kb].hi;
+            }
+            return;
         }
         const __amdgpu_buffer_rsrc_t rh2 = rows_rsrc(a.h2[p], row0, a.B, H2P), rh1 = rows_rsrc(a.h1[p], row0, a.B, H1P);
 #pragma unroll
@@ -368,8 +398,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             if (HOIST && have_pre) R = Rpre; else fetch_rows(tile, p, R);
             have_pre = false;
             f32x4 (&dml)[2] = R.dml;
-            f32x4 (&h2)[H2T] = R.h2;
-            f32x4 (&h1)[H1T] = R.h1;
+            auto& h2 = R.h2;
+            auto& h1 = R.h1;
+            // ReLU gate of tile mt from the fp32 tile or, packed form, from the bf16 halves of its operand (relu output >= +0:
+            // positive <=> the 16 bits are not zero)
+            auto gate_h2 = [&](int mt, f32x4 acc) { return HPK ? bf_gate(acc, R.h2p[HPK ? mt >> 1 : 0], mt & 1) : gate4(acc, h2[HPK ? 0 : mt]); };
+            auto gate_h1 = [&](int mt, f32x4 acc) { return HPK ? bf_gate(acc, R.h1p[HPK ? mt >> 1 : 0], mt & 1) : gate4(acc, h1[HPK ? 0 : mt]); };
             // (dW3~ += dml * h2^T is staged and computed together with the layer-1 wgrad below: the B staging buffer is
             // free in that round because x never goes through LDS - 4 instead of 6 barriers per pass)
             VPC_STAMP(1);
@@ -381,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
 #pragma unroll
             for (int mt = 0; mt < H2T; ++mt) {
                 if (PREC == PREC_F32) dh2[mt] = gate4(tile_T<2, 64>(W3, mt, dml, zero4(), cc, qq), h2[mt]);
-                else dh2[mt] = gate4(bf_tile_T<PREC, 1, 64>(W3, mt, dmlb, zero4(), 16 * qq + cc), h2[mt]);
+                else dh2[mt] = gate_h2(mt, bf_tile_T<PREC, 1, 64>(W3, mt, dmlb, zero4(), 16 * qq + cc));
             }
             if (BF) bf_acts<PREC, H2T>(dh2, dh2b);
             VPC_STAMP(2);
@@ -391,8 +425,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             if (BF && !ABLE(1)) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 7, H2T>(sAh, sAl, 16 * w + cc, kb, qq, dh2b[kb]);
+                if (HPK) {
 #pragma unroll
-                for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h1[t]);
+                    for (int kb = 0; kb < 4; ++kb) bf_stage_write_op<PREC, 7, H1T>(sBh, sBl, 16 * w + cc, kb, qq, R.h1p[kb]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h1[HPK ? 0 : t]);
+                }
             } else if (!ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dh2[t], sb);
@@ -454,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             // basic blocks in the middle of the dgrad MFMA stream)
             if (BF) {
                 bf_layer_T<PREC, 2, 128, H1T, 4, 2>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                    dh1[mt] = gate4(acc, h1[mt]);
+                    dh1[mt] = gate_h1(mt, acc);
                     dbacc[mt] += dh1[mt];
                 });
             } else {
@@ -471,8 +510,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             if (BF && !ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sAh, sAl, 16 * w + cc, t, qq, dh1[t]);
+                if (HPK) {
 #pragma unroll
-                for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h2[t]);
+                    for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 7, H2T>(sBh, sBl, 16 * w + cc, kb, qq, R.h2p[kb]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, h2[HPK ? 0 : t]);
+                }
                 bf_stage_write_op<PREC, 7, 6>(sBh, sBl, 16 * w + cc, H2T / 2, qq, dmlb[0]);  // tiles 4, 5
             } else if (!ABLE(1)) {
 #pragma unroll
