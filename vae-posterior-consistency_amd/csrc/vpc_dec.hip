@@ -44,6 +44,13 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
     float* stA = lds + im.total;   // [NA][CH]   A operands of wgrad (dY)
     float* stB = stA + NA * CH;    // [112][CH]  B operands of wgrad (activations)
     float* red = BF ? stA : stB + H1P * CH;   // [DEC_WAVES][8] (bf16 image: at the LDS limit, aliases the staging buffer)
+    // bf16 engine: the wgrad operands of the 64 staged rows as bf16 blocks, hi plane + lo plane (vpc_bf16.h, bf_stage_*);
+    // FTA tile slots per A row (dpre has DT tiles, dg2 7, dg1 4), 7 per B row - the buffers keep their fp32 sizes
+    constexpr int FTA = DT == 8 ? 8 : 7, SKB = CH / 32;
+    float* sAh = stA;
+    float* sAl = stA + CH * 8 * FTA;
+    float* sBh = stB;
+    float* sBl = stB + CH * 56;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int colbase = 16 * w;
     int sb[4];  // per-lane element offsets of the wgrad staging writes (tile 0); tiles add a compile-time constant
@@ -373,25 +380,29 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
+                        if (BF) {
 #pragma unroll
-                        for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[ch][t], sb);
+                            for (int t = 0; t < DT; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dpre[ch][t]);
 #pragma unroll
-                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[ch][t], sb);
+                            for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, g2[ch][t]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < DT; ++t) stage_write_b<CH>(stA, t, dpre[ch][t], sb);
+#pragma unroll
+                            for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[ch][t], sb);
+                        }
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
                         if (BF) {
 #pragma unroll
-                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                            for (int sb2 = 0; sb2 < SKB; ++sb2) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 BfOp fa[I6];
 #pragma unroll
-                                for (int i = 0; i < I6; ++i)
-                                    fa[i] = bf_pack<PREC>(stage_frag<CH>(stA, (w + 4 * i) % DT, 2 * sb2, cc, qq),
-                                                          stage_frag<CH>(stA, (w + 4 * i) % DT, 2 * sb2 + 1, cc, qq));
+                                for (int i = 0; i < I6; ++i) fa[i] = bf_stage_frag<PREC, FTA>(sAh, sAl, (w + 4 * i) % DT, sb2, 16 * qq + cc);
 #pragma unroll
                                 for (int nt = 0; nt < H1T; ++nt) {
-                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
-                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+                                    const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, nt, sb2, 16 * qq + cc);
 #pragma unroll
                                     for (int i = 0; i < I6; ++i)
                                         if (w + 4 * i < DT) acc6[i][nt] = bf_mma<PREC>(fa[i], fb, acc6[i][nt]);
@@ -454,24 +465,28 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
+                        if (BF) {
 #pragma unroll
-                        for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[ch][t], sb);
+                            for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dg2[ch][t]);
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[ch][t], sb);
+                            for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, t, qq, g1[ch][t]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stA, t, dg2[ch][t], sb);
+#pragma unroll
+                            for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[ch][t], sb);
+                        }
                         __syncthreads();
                         if (VPC_DBG(1)) continue;
                         if (BF) {
 #pragma unroll
-                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
+                            for (int sb2 = 0; sb2 < SKB; ++sb2) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                const BfOp fa0 = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
-                                                               stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
-                                const BfOp fa1 = bf_pack<PREC>(stage_frag<CH>(stA, (w + 4) % H1T, 2 * sb2, cc, qq),
-                                                               stage_frag<CH>(stA, (w + 4) % H1T, 2 * sb2 + 1, cc, qq));
+                                const BfOp fa0 = bf_stage_frag<PREC, FTA>(sAh, sAl, w, sb2, 16 * qq + cc);
+                                const BfOp fa1 = bf_stage_frag<PREC, FTA>(sAh, sAl, (w + 4) % H1T, sb2, 16 * qq + cc);
 #pragma unroll
                                 for (int nt = 0; nt < H2T; ++nt) {
-                                    const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, nt, 2 * sb2, cc, qq),
-                                                                  stage_frag<CH>(stB, nt, 2 * sb2 + 1, cc, qq));
+                                    const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, nt, sb2, 16 * qq + cc);
                                     acc5[0][nt] = bf_mma<PREC>(fa0, fb, acc5[0][nt]);
                                     if (w + 4 < H1T) acc5[1][nt] = bf_mma<PREC>(fa1, fb, acc5[1][nt]);
                                 }
@@ -529,17 +544,21 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
                         __syncthreads();
+                        if (BF) {
 #pragma unroll
-                        for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[ch][t], sb);
-                        stage_write_b<CH>(stB, 0, z[ch][0], sb);
+                            for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dg1[ch][t]);
+                            bf_stage_write<PREC, 7>(sBh, sBl, 16 * w + cc, 0, qq, z[ch][0]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[ch][t], sb);
+                            stage_write_b<CH>(stB, 0, z[ch][0], sb);
+                        }
                         __syncthreads();
                         if (BF) {
 #pragma unroll
-                            for (int sb2 = 0; sb2 < CH / 32; ++sb2) {
-                                const BfOp fa = bf_pack<PREC>(stage_frag<CH>(stA, w, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stA, w, 2 * sb2 + 1, cc, qq));
-                                const BfOp fb = bf_pack<PREC>(stage_frag<CH>(stB, 0, 2 * sb2, cc, qq),
-                                                              stage_frag<CH>(stB, 0, 2 * sb2 + 1, cc, qq));
+                            for (int sb2 = 0; sb2 < SKB; ++sb2) {
+                                const BfOp fa = bf_stage_frag<PREC, FTA>(sAh, sAl, w, sb2, 16 * qq + cc);
+                                const BfOp fb = bf_stage_frag<PREC, 7>(sBh, sBl, 0, sb2, 16 * qq + cc);
                                 acc4 = bf_mma<PREC>(fa, fb, acc4);
                             }
                             continue;
