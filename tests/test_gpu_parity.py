@@ -557,6 +557,31 @@ def test_eval_vae_matches_oracle(kind, tmp_path, monkeypatch):
         assert os.path.exists(pth)
 
 
+@pytest.mark.parametrize("d,B", [(128, 300), (14, 64)])
+def test_mask_dtypes_give_one_result(d, B):
+    """The kernels convert mask BYTES with v_cvt_f32_ubyte, so the C ABI takes 0 / 1 bytes (include/vpc.h); the host side
+    accepts what the reference passes around - bool masks, float masks, and uint8 masks with any non-zero value for
+    "observed" (normalised by ops.as_mask_u8).  All of them must give the bool-mask result bit for bit."""
+    params = O.init_params(d, L, seed=5)
+    x, mask, mask_p, eq, ep = (t.to(DEV) for t in synth(B, d, seed=11))
+    forms = {"bool": (mask, mask_p), "float": (mask.float(), mask_p.float()),
+             "u8_255": (mask.to(torch.uint8) * 255, mask_p.to(torch.uint8) * 7),
+             "u8_01": (mask.to(torch.uint8), mask_p.to(torch.uint8))}
+    res = {}
+    for name, (mk, mp) in forms.items():
+        tr = vpc.FusedTrainer(make_model(vpc.Reg_VAE, d, params))
+        tr.step(x, mk, mp, eq, ep, alpha=0.8, beta=0.9, update=False)
+        res[name] = (tr.loss_value(), tr.grad.clone())
+    for name in ("float", "u8_255", "u8_01"):
+        assert res[name][0] == res["bool"][0], name
+        assert torch.equal(res[name][1], res["bool"][1]), name
+    # the API path (encoder with a uint8 mask of 255s)
+    m = make_model(vpc.Reg_VAE, d, params)
+    za, _, _ = m.encoder(x, mask, sample=False)
+    zb, _, _ = m.encoder(x, mask.to(torch.uint8) * 255, sample=False)
+    assert torch.equal(za, zb)
+
+
 @pytest.mark.parametrize("cls", ["Reg_VAE", "vanilla_VAE"])
 def test_graph_replay_matches_eager_steps(cls):
     """FusedTrainer.step_graph (captured HIP graph, device-side step / RNG counters) == the same steps run eagerly:
