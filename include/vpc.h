@@ -258,11 +258,16 @@ int vpc_linear_dgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
                      int K, int precision, void* stream);
 
 /* dw[N][K] (+)= (dy * act'(y_gate))^T x,  db[N] (+)= column sums; split over M into per-workgroup partials in
- * `scratch` (vpc_linear_wgrad_scratch floats) that are summed in a fixed order.  db may be NULL. */
+ * `scratch` (vpc_linear_wgrad_scratch floats) that are summed in a fixed order.  db may be NULL.
+ * dw == NULL: only the partials are written (one launch); vpc_linear_wgrad_reduce then sums the partials of up to 8 such
+ * calls - each with its own scratch buffer, HOST arrays of n_layers entries - in ONE launch, with the same summation order
+ * (the fused MNAR step: 6 weight gradients, 7 launches instead of 12). */
 long vpc_linear_wgrad_scratch(long M, int N, int K);
 int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
                      int K, int accumulate, int precision, void* stream);
+int vpc_linear_wgrad_reduce(int n_layers, const float* const* scratch, const long* M, const int* N, const int* K,
+                            float* const* dw, float* const* db, const int* accumulate, void* stream);
 
 /* z[b*K+k][:] = mean[b] + eps[b][k] * exp(logvar[b]/2), heads = [mean L | logvar L]; eps NULL -> z = mean
  * (encoder, VAE.py:2382-2391 / :2753-2765) and its backward (sum over the K replicas, plus g_heads if given). */

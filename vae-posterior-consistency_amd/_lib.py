@@ -70,6 +70,7 @@ _PROTOS = {
     "vpc_linear_dgrad": [P, L_, P, L_, I, I, P, P, L_, I, P, L_, L_, I, I, I, P],
     "vpc_linear_wgrad_scratch": [L_, I, I],
     "vpc_linear_wgrad": [P, L_, P, L_, I, I, P, L_, P, P, P, L_, L_, I, I, I, I, P],
+    "vpc_linear_wgrad_reduce": [I, PP, C.POINTER(L_), IP, IP, PP, PP, IP, P],
     "vpc_nm_sample": [P, L_, P, P, L_, L_, I, I, P],
     "vpc_nm_sample_bwd": [P, L_, P, P, L_, P, L_, P, L_, L_, I, I, P],
     "vpc_nm_mul": [P, P, P, L_, P],

@@ -365,6 +365,38 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float*
     if (dst) *dst = accumulate ? *dst + s : s;
 }
 
+// the same for up to WGRAD_MANY layers in ONE launch (the fused MNAR step defers its six reductions to the end of the
+// backward pass: at the reference's batch sizes every launch is a dependent ~7 us dispatch)
+constexpr int WGRAD_MANY = 8;
+struct WgradMany {
+    const float* part[WGRAD_MANY]; float* dW[WGRAD_MANY]; float* db[WGRAD_MANY];
+    int S[WGRAD_MANY], N[WGRAD_MANY], K[WGRAD_MANY], accumulate[WGRAD_MANY], first_block[WGRAD_MANY + 1];
+    int n;
+};
+__global__ void wgrad_reduce_many_kernel(WgradMany a) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < WGRAD_MANY; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.first_block[i]) l = i;
+    const long n_w = (long)a.N[l] * a.K[l];
+    const long i = (long)(blockIdx.x - a.first_block[l]) * blockDim.x + threadIdx.x;
+    if (i >= n_w + a.N[l]) return;
+    const bool is_w = i < n_w;
+    const float* src = is_w ? a.part[l] + i : a.part[l] + (long)a.S[l] * n_w + (i - n_w);
+    const long stride = is_w ? n_w : a.N[l];
+    const int S = a.S[l];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // the association of wgrad_reduce_kernel: bit-identical results
+    int sp = 0;
+    for (; sp + 3 < S; sp += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += src[(long)(sp + u) * stride];
+    }
+    for (; sp < S; ++sp) acc[0] += src[(long)sp * stride];
+    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float* dst = is_w ? a.dW[l] + i : (a.db[l] ? a.db[l] + (i - n_w) : nullptr);
+    if (dst) *dst = a.accumulate[l] ? *dst + s : s;
+}
+
 static bool vec_ok(const void* p, long ld) { return aligned16(p) && (ld % 4) == 0; }
 
 template <int MODE, bool RAGGED, int JT, int PREC>
@@ -440,7 +472,7 @@ long vpc_linear_wgrad_scratch(long M, int N, int K) {
 int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg, int gate, int gate_split,
                      const float* x, long ldx, float* dw, float* db, float* scratch, long scratch_floats, long M, int N,
                      int K, int accumulate, int precision, void* stream) {
-    if (!dy || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || M > 0x7fffff00L)
+    if (!dy || !x || !scratch || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || M > 0x7fffff00L)
         return VPC_ERR_ARG;
     if (precision < 0 || precision > 2) return VPC_ERR_ARG;
     if (y_gate && ldyg < N) return VPC_ERR_ARG;
@@ -459,10 +491,30 @@ int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     const dim3 grid((unsigned)S, (unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128));
     const bool ragged = (N % 64) != 0 || (K % 64) != 0;
     int rc = ragged ? launch_one<LIN_WGRAD, true, 4>(a, grid, precision, st) : launch_one<LIN_WGRAD, false, 4>(a, grid, precision, st);
-    if (rc != VPC_OK) return rc;
+    if (rc != VPC_OK || !dw) return rc;  // dw == NULL: partials only, summed later by vpc_linear_wgrad_reduce
     const long n = (long)N * K + N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch,
                        a.bias_part, (int)S, N, K, dw, db, accumulate);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+int vpc_linear_wgrad_reduce(int n_layers, const float* const* scratch, const long* M, const int* N, const int* K,
+                            float* const* dw, float* const* db, const int* accumulate, void* stream) {
+    if (n_layers < 1 || n_layers > WGRAD_MANY || !scratch || !M || !N || !K || !dw || !accumulate) return VPC_ERR_ARG;
+    WgradMany a{};
+    a.n = n_layers;
+    int blocks = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!scratch[l] || !dw[l] || M[l] <= 0 || N[l] <= 0 || K[l] <= 0) return VPC_ERR_ARG;
+        const long per = (long)N[l] * K[l] + N[l];
+        a.part[l] = scratch[l]; a.dW[l] = dw[l]; a.db[l] = db ? db[l] : nullptr;
+        a.S[l] = (int)(vpc_linear_wgrad_scratch(M[l], N[l], K[l]) / per);  // the split count vpc_linear_wgrad used
+        a.N[l] = N[l]; a.K[l] = K[l]; a.accumulate[l] = accumulate[l];
+        a.first_block[l] = blocks;
+        blocks += (int)((per + 255) / 256);
+    }
+    a.first_block[n_layers] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

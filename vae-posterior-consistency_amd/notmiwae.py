@@ -12,6 +12,7 @@ adjacent in one flat parameter buffer, so each pair is ONE GEMM.  No CPU fallbac
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -49,12 +50,27 @@ def _wgrad_scratch(device, floats):
 
 
 def linear_wgrad(dy, x, dw, db, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=0, accumulate=False, lddy=None,
-                 ldx=None, precision=0):
+                 ldx=None, precision=0, scratch=None):
+    """dw = None: write only the per-split partials into `scratch` (the caller's own buffer for this layer); they are summed
+    later, together with other layers', by wgrad_reduce (one launch)."""
     need = int(lib().vpc_linear_wgrad_scratch(M, N, K))
-    sc = _wgrad_scratch(dy.device, need)
+    sc = _wgrad_scratch(dy.device, need) if scratch is None else scratch
     check(lib().vpc_linear_wgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(x), ldx or K,
                                  ptr(dw), ptr(db), ptr(sc), sc.numel(), M, N, K, int(accumulate), int(precision),
                                  stream_ptr()), "vpc_linear_wgrad")
+
+
+def wgrad_reduce(layers):
+    """layers: [(scratch, M, N, K, dw, db, accumulate)] of linear_wgrad(dw=None) calls -> all gradients in ONE launch."""
+    n = len(layers)
+    sc = (C.c_void_p * n)(*[t[0].data_ptr() for t in layers])
+    Ms = (C.c_long * n)(*[int(t[1]) for t in layers])
+    Ns = (C.c_int * n)(*[int(t[2]) for t in layers])
+    Ks = (C.c_int * n)(*[int(t[3]) for t in layers])
+    dw = (C.c_void_p * n)(*[t[4].data_ptr() for t in layers])
+    db = (C.c_void_p * n)(*[None if t[5] is None else t[5].data_ptr() for t in layers])
+    acc = (C.c_int * n)(*[int(bool(t[6])) for t in layers])
+    check(lib().vpc_linear_wgrad_reduce(n, sc, Ms, Ns, Ks, dw, db, acc, stream_ptr()), "vpc_linear_wgrad_reduce")
 
 
 def nm_sample(heads, eps, z, B, K, Ld):
@@ -556,6 +572,14 @@ class NMTrainer:
         self.G, self.gheads, self.dht = e(M, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
         self.dg2, self.dg1, self.dz = e(M, HID), e(M, HID), e(M, Ld)
         self.dh2, self.dh1 = e(R, HID), e(R, HID)
+        # per-layer partial buffers of the six weight gradients (summed by ONE launch at the end of the backward pass)
+        self.wg_shapes = [(M, 2 * d, HID), (M, HID, HID), (M, HID, Ld), (R, 2 * Ld, HID), (R, HID, HID), (R, HID, d)]
+        sizes = [int(lib().vpc_linear_wgrad_scratch(*sh)) for sh in self.wg_shapes]
+        buf = e(sum(sizes))
+        self.wg_scratch, o = [], 0
+        for n in sizes:
+            self.wg_scratch.append(buf[o:o + n])
+            o += n
         nbytes = int(lib().vpc_nm_loss_scratch(B, d))
         self.scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
         self._B = B
@@ -629,19 +653,33 @@ class NMTrainer:
           B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
         # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
         g = self.g
-        t("dec_wgrad3", linear_wgrad, G, self.g2, g["Wx"], g["bx"], M, 2 * d, HID, precision=self.prec)
+        # weight gradients: partials per layer, all summed by one launch after the last one (6 reduction launches less;
+        # the timer mode keeps the per-layer form so that every entry brackets a complete gradient)
+        defer = self.timers is None
+        pend = []
+
+        def wgrad(name, i, dy, xx, dw, db):
+            Mi, Ni, Ki = self.wg_shapes[i]
+            if not defer:
+                return t(name, linear_wgrad, dy, xx, dw, db, Mi, Ni, Ki, precision=self.prec)
+            linear_wgrad(dy, xx, None, None, Mi, Ni, Ki, precision=self.prec, scratch=self.wg_scratch[i])
+            pend.append((self.wg_scratch[i], Mi, Ni, Ki, dw, db, False))
+
+        wgrad("dec_wgrad3", 0, G, self.g2, g["Wx"], g["bx"])
         t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, precision=self.prec)
-        t("dec_wgrad2", linear_wgrad, self.dg2, self.g1, g["Wd2"], g["bd2"], M, HID, HID, precision=self.prec)
+        wgrad("dec_wgrad2", 1, self.dg2, self.g1, g["Wd2"], g["bd2"])
         t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU, precision=self.prec)
-        t("dec_wgrad1", linear_wgrad, self.dg1, self.z, g["Wd1"], g["bd1"], M, HID, Ld, precision=self.prec)
+        wgrad("dec_wgrad1", 2, self.dg1, self.z, g["Wd1"], g["bd1"])
         t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld, precision=self.prec)
         t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
           K, Ld)
-        t("enc_bwd", linear_wgrad, self.dht, self.h2, g["Wh"], g["bh"], R, 2 * Ld, HID, precision=self.prec)
+        wgrad("enc_bwd", 3, self.dht, self.h2, g["Wh"], g["bh"])
         t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU, precision=self.prec)
-        t("enc_bwd", linear_wgrad, self.dh2, self.h1, g["We2"], g["be2"], R, HID, HID, precision=self.prec)
+        wgrad("enc_bwd", 4, self.dh2, self.h1, g["We2"], g["be2"])
         t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU, precision=self.prec)
-        t("enc_bwd", linear_wgrad, self.dh1, self.xin, g["We1"], g["be1"], R, HID, d, precision=self.prec)
+        wgrad("enc_bwd", 5, self.dh1, self.xin, g["We1"], g["be1"])
+        if pend:
+            wgrad_reduce(pend)
         if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
             from . import dist as dp_mod
             if not getattr(self, "_coll_ready", False):
