@@ -53,15 +53,18 @@ def linear_wgrad(dy, x, dw, db, M, N, K, y_gate=None, gate=ACT_NONE, gate_split=
                  ldx=None, precision=0, scratch=None):
     """dw = None: write only the per-split partials into `scratch` (the caller's own buffer for this layer); they are summed
     later, together with other layers', by wgrad_reduce (one launch)."""
-    need = int(lib().vpc_linear_wgrad_scratch(M, N, K))
-    sc = _wgrad_scratch(dy.device, need) if scratch is None else scratch
+    sc = _wgrad_scratch(dy.device, int(lib().vpc_linear_wgrad_scratch(M, N, K))) if scratch is None else scratch
     check(lib().vpc_linear_wgrad(ptr(dy), lddy or N, ptr(y_gate), lddy or N, gate, gate_split, ptr(x), ldx or K,
                                  ptr(dw), ptr(db), ptr(sc), sc.numel(), M, N, K, int(accumulate), int(precision),
                                  stream_ptr()), "vpc_linear_wgrad")
 
 
-def wgrad_reduce(layers):
-    """layers: [(scratch, M, N, K, dw, db, accumulate)] of linear_wgrad(dw=None) calls -> all gradients in ONE launch."""
+def wgrad_reduce(layers, cache=None):
+    """layers: [(scratch, M, N, K, dw, db, accumulate)] of linear_wgrad(dw=None) calls -> all gradients in ONE launch.
+    `cache` (a dict owned by the caller): the argument arrays are built once per set of buffers, not per step."""
+    if cache is not None and "args" in cache:
+        check(lib().vpc_linear_wgrad_reduce(*cache["args"], stream_ptr()), "vpc_linear_wgrad_reduce")
+        return
     n = len(layers)
     sc = (C.c_void_p * n)(*[t[0].data_ptr() for t in layers])
     Ms = (C.c_long * n)(*[int(t[1]) for t in layers])
@@ -70,6 +73,8 @@ def wgrad_reduce(layers):
     dw = (C.c_void_p * n)(*[t[4].data_ptr() for t in layers])
     db = (C.c_void_p * n)(*[None if t[5] is None else t[5].data_ptr() for t in layers])
     acc = (C.c_int * n)(*[int(bool(t[6])) for t in layers])
+    if cache is not None:
+        cache["args"] = (n, sc, Ms, Ns, Ks, dw, db, acc)
     check(lib().vpc_linear_wgrad_reduce(n, sc, Ms, Ns, Ks, dw, db, acc, stream_ptr()), "vpc_linear_wgrad_reduce")
 
 
@@ -576,6 +581,7 @@ class NMTrainer:
         self.wg_shapes = [(M, 2 * d, HID), (M, HID, HID), (M, HID, Ld), (R, 2 * Ld, HID), (R, HID, HID), (R, HID, d)]
         sizes = [int(lib().vpc_linear_wgrad_scratch(*sh)) for sh in self.wg_shapes]
         buf = e(sum(sizes))
+        self._wg_cache = {}
         self.wg_scratch, o = [], 0
         for n in sizes:
             self.wg_scratch.append(buf[o:o + n])
@@ -679,7 +685,7 @@ class NMTrainer:
         t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU, precision=self.prec)
         wgrad("enc_bwd", 5, self.dh1, self.xin, g["We1"], g["be1"])
         if pend:
-            wgrad_reduce(pend)
+            wgrad_reduce(pend, self._wg_cache)  # (buffers and gradient views are fixed for a batch size: arrays built once)
         if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
             from . import dist as dp_mod
             if not getattr(self, "_coll_ready", False):
