@@ -50,33 +50,51 @@ def flops_per_sample(d, L, passes=2):
     enc = enc_f + (2 * enc_f - d * 100)
     dec = 3 * dec_f
     return dict(total=2 * passes * (enc + dec), decoder_fused=2 * passes * dec, encoder_fwd=2 * passes * enc_f,
-                encoder_bwd=2 * passes * (2 * enc_f - d * 100))
+                encoder_bwd=2 * passes * (2 * enc_f - d * 100), step_fused=2 * passes * (enc + dec))
 
 
-def measured_traffic(B, d, L, precision="f32"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  PMC counters cannot be read from inside this process, so
-    the number is the one measured with `rocprofv3 --pmc` on this same command; None for other shapes."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if (B, d, L) == (65536, 128, 10):
-            ks = t["precisions"][precision]
-            return next(v["hbm_bytes_corrected"] for k, v in ks.items() if "dec8" in k)
-    except Exception:
-        pass
+def _traffic_table():
+    """Committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, mean per dispatch): the newest
+    round's file that exists.  PMC counters cannot be read from inside this process, so these are the numbers measured with
+    `rocprofv3 --pmc` on this same command (tools/pmc_r03.sh)."""
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
     return None
 
 
-def measured_step_traffic(B, d, L, precision="f32"):
-    """HBM bytes per STEP: the three MFMA kernels from the committed PMC passes (profiles/r02_traffic.json) plus the
-    algorithmic traffic of the two small launches (reduce_step reads 256 partial blocks = 49 MB and writes < 1 MB; draw_step
-    reads the mask and writes mask_p + eps = 22 MB).  None for shapes / precisions without a PMC pass."""
+def measured_traffic(B, d, L, precision="f32", dom="decoder_fused"):
+    """HBM bytes per launch of the dominant kernel; None for shapes / precisions without a PMC pass."""
+    t = _traffic_table()
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if (B, d, L) != (65536, 128, 10):
+        if t is None or (B, d, L) != (65536, 128, 10):
             return None
-        ks = t["precisions"]["bf16x3" if precision == "bf16" else precision]  # bf16 moves the same bytes as bf16x3
-        return sum(v["hbm_bytes_corrected"] for v in ks.values()) + 49_000_000 + 22_000_000
+        ks = t["precisions"][precision]
+        key = "step_bf16" if dom == "step_fused" else "dec8"
+        return next(v["hbm_bytes_corrected"] for k, v in ks.items() if key in k)
+    except Exception:
+        return None
+
+
+def measured_step_traffic(B, d, L, precision="f32", dom="decoder_fused"):
+    """HBM bytes per STEP: every kernel of the step that has a PMC pass; launches without one are priced at their
+    algorithmic traffic (reduce_step reads the partial blocks = 49 MB and writes < 1 MB; draw_step reads the mask and
+    writes mask_p + eps = 22 MB).  None for shapes / precisions without a PMC pass."""
+    t = _traffic_table()
+    try:
+        if t is None or (B, d, L) != (65536, 128, 10):
+            return None
+        ks = t["precisions"][precision]
+        if dom == "step_fused" and not any("step_bf16" in k for k in ks):
+            return None
+        tot = sum(v["hbm_bytes_corrected"] for v in ks.values())
+        if not any("reduce_step" in k for k in ks):
+            tot += 49_000_000
+        if not any("draw_step" in k for k in ks):
+            tot += 22_000_000
+        return tot
     except Exception:
         return None
 
@@ -120,40 +138,56 @@ def cpu_baseline(B, d, L, seconds=20.0, threads=None):
                                 sample=f"{n_on} {what}, torch.autograd.set_detect_anomaly(True) as imputation.py:19"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU (weak) / global rows (strong)")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--latent", type=int, default=10)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32",
-                    help="f32 = the headline (exact fp32 MFMA); bf16x3 / bf16 = extra lines on v_mfma_f32_16x16x32_bf16")
-    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the loop rotates over")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-settle", action="store_true", help="skip the settle steps after the W warm-up steps")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--cpu-threads", type=int, default=None)
-    args = ap.parse_args()
+def mnar_flops_per_sample(d, L, K, H=128, passes=2):
+    """Algorithmic FLOP per data row of the MNAR step (REG_notMIWAE_v2, src/models/VAE.py:2327-2505): encoder
+    d->H->H->(L|L) once per pass, decoder L->H->H->(d|d) on K samples per row; backward 2x forward minus the dgrad to x."""
+    enc = d * H + H * H + H * 2 * L
+    dec = K * (L * H + H * H + H * 2 * d)
+    return 2 * passes * (3 * (enc + dec) - d * H)
 
-    import vpc_amd as vpc
-    rank, world, local = vpc.dp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N rank processes as a `python -m torch.distributed.run`
+    CHILD - this parent has not touched the GPU (torch.cuda.device_count() does not initialise it) - and exit with its code.
+    Fails non-zero instead of measuring fewer GPUs than asked for."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("VPC_DIST_BACKEND") == "gloo"  # N ranks sharing the visible device(s) / the CPU
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) are visible; refusing to measure fewer GPUs than asked for "
+              f"(VPC_DIST_BACKEND=gloo rehearses the multi-rank path on what is there)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(vpc, tr, world, dev):
+    """Ranks the step's OWN collective carrier sums over (1 per rank through tr's carrier): what `n_gpus` reports."""
+    if world == 1:
+        return 1
+    one = torch.ones(1, device=dev)
+    vpc.dp.allreduce_bucket(one, None, tr._collective())
+    torch.cuda.synchronize()
+    return int(round(float(one.item())))
+
+
+def measure(vpc, args, rank, world, dev, scaling):
+    """Warm-up, settle, EXACTLY args.steps timed steps (barrier + synchronize on both sides, MAX over ranks) of the
+    headline step in one scaling mode; returns the raw numbers (every rank) - rank 0 formats them."""
     d, Ld = args.dim, args.latent
-    if args.scaling == "strong":
+    if scaling == "strong":
         Bg = args.batch
         lo, hi = vpc.dp.shard_rows(Bg, rank, world)
         B = hi - lo
     else:
         B, Bg, lo = args.batch, args.batch * world, rank * args.batch
-
     torch.manual_seed(0)
     model = vpc.Reg_VAE(d, 500, 10, Ld, {"batch_size": B, "patience": 100}, "bench", "kl_reg").to(dev)
     flat = model.flatten_parameters()
@@ -180,6 +214,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    dom = tr.dominant_launch()  # "decoder_fused", or "step_fused" when the three MFMA kernels are one launch
     # CPython's generation-2 garbage collection fires once around step 70 of the timed loop (the ctypes argument arrays of
     # ~350 launches) and, with torch's millions of live objects, pauses the host for 20-40 ms - longer than the work
     # queued on the GPU at that point (rocprofv3 trace: one 38 ms gap, nothing else).  Collect here, BEFORE the settle
@@ -190,7 +225,7 @@ def main():
     # settle: until the dominant kernel's event time is stable (all ranks run the same number of groups)
     settle = 0
     if not args.no_settle:
-        tr.timers, tr.timer_names, tr.timer_every = {}, {"decoder_fused"}, 1
+        tr.timers, tr.timer_names, tr.timer_every = {}, {dom}, 1
         prev = None
         for _ in range(40):
             tr.timers.clear()
@@ -198,7 +233,7 @@ def main():
                 step()
             settle += 8
             torch.cuda.synchronize()
-            cur = statistics.mean(a.elapsed_time(b) for a, b in tr.timers["decoder_fused"])
+            cur = statistics.mean(a.elapsed_time(b) for a, b in tr.timers[dom])
             done = prev is not None and abs(cur - prev) <= 0.015 * prev
             if world > 1:
                 flag = torch.tensor([1.0 if done else 0.0], device=dev)
@@ -212,7 +247,7 @@ def main():
     tr.epoch_total()  # reset the device-side loss accumulator: loss_mean below covers the timed steps only
     # Inside the timed region only the dominant kernel is bracketed by HIP events (every 8th step); the other launches
     # are sampled right after the region.
-    tr.timers, tr.timer_names = {}, {"decoder_fused"}
+    tr.timers, tr.timer_names = {}, {dom}
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -222,7 +257,7 @@ def main():
     gc.enable()
     total = tr.epoch_total()  # one host read per "epoch", as train.py:118 (the timed steps only)
     timers, tr.timers = tr.timers, {}
-    tr.timer_names, tr.timer_every = {"encoder_fwd", "encoder_bwd"}, 2
+    tr.timer_names, tr.timer_every = {"encoder_fwd", "encoder_bwd", "draw_step", "reduce_step"}, 2
     for _ in range(16):
         step()
     sync()
@@ -237,27 +272,183 @@ def main():
         tr.loss_value()
     sync()
     per_step_sync_ms = (time.perf_counter() - t1) / n_sync * 1e3
+    seen = ranks_seen(vpc, tr, world, dev)
     if world > 1:
         t = torch.tensor([elapsed, per_step_sync_ms], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, per_step_sync_ms = float(t[0].item()), float(t[1].item())
         torch.distributed.barrier()
+    kern_ms = {k: statistics.mean(a.elapsed_time(b) for a, b in v) for k, v in timers.items()}
+    return dict(B=B, Bg=Bg, elapsed=elapsed, per_step_sync_ms=per_step_sync_ms, total=total, settle=settle, kern_ms=kern_ms,
+                dom=dom, small=tr.last_blocks[1] > (B + 127) // 128, seen=seen, value=Bg * args.steps / elapsed,
+                ms_step=elapsed / args.steps * 1e3)
+
+
+def timed_steps(fn, warm, n):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def extra_configs(vpc, dev):
+    """BASELINE configs 2, 3 and 5 at the reference's own sizes, in this process, after the headline region (each variant
+    gets >= 120 warm-up steps: the first launches of a kernel variant carry one-time costs, profiles/r02_notes.md).
+    Synthetic stand-ins of the right shape ("UCI gas" = 13 910 x 128, MCAR 30 %): no datasets ship with the reference."""
+    out = []
+    TP = {"batch_size": 64, "patience": 100}
+    N, d, Ld = 13910, 128, 10
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, d, generator=g).to(dev)
+    m = (torch.rand(N, d, generator=g) < 0.7).to(dev)
+    fl = flops_per_sample(d, Ld)["total"]
+    # config 2: Reg_VAE kl_reg, batch 64 (Data/imputation_args.json), fused step incl. draws and Adam
+    for prec in ("f32", "bf16"):
+        try:
+            torch.manual_seed(0)
+            model = vpc.Reg_VAE(d, 500, 10, Ld, TP, "bench", "kl_reg").to(dev)
+            tr = vpc.FusedTrainer(model, precision=prec)
+            bs = [(x[i:i + 64], m[i:i + 64]) for i in range(0, N - 63, 64)]
+            k = [0]
+
+            def st():
+                xb, mb = bs[k[0] % len(bs)]
+                k[0] += 1
+                tr.step(xb, mb, alpha=1.0, p_missingness=30)
+            dt = timed_steps(st, 160, 2 * len(bs))
+            out.append(dict(config=2, workload="UCI gas stand-in 13910x128 MCAR, Reg_VAE kl_reg, batch 64, fused step",
+                            dtype=prec, us_per_step=dt * 1e6, samples_per_s=64 / dt,
+                            roofline=dict(bound="mfma", achieved=fl * 64 / dt / 1e12, peak=PEAK[prec], unit="TFLOP/s",
+                                          frac=fl * 64 / dt / 1e12 / PEAK[prec],
+                                          note="whole step incl. draws and Adam; latency-bound at this batch")))
+            del tr, model
+        except Exception as e:  # an extra line must never take the headline down
+            out.append(dict(config=2, dtype=prec, error=repr(e)[:200]))
+    # config 3: REG_notMIWAE_v2, batch 128, K = 20, p_missingness 50 (Data/imputation_args_mnar.json:1-2)
+    for prec in ("f32", "bf16"):
+        try:
+            from vpc_amd import notmiwae as nm
+            K = 20
+            mf = m.float()
+            torch.manual_seed(0)
+            model = nm.REG_notMIWAE_v2(d, 128, 10, Ld, {"batch_size": 128, "patience": 1}, K, 1).to(dev)
+            tr = nm.NMTrainer(model, precision=prec)
+            bs = [(x[i:i + 128], mf[i:i + 128]) for i in range(0, N - 127, 128)]
+            k = [0]
+
+            def st3():
+                xb, mb = bs[k[0] % len(bs)]
+                k[0] += 1
+                tr.step(xb, mb, alpha=0.5, p_missingness=50)
+            dt = timed_steps(st3, 160, 2 * len(bs))
+            f3 = mnar_flops_per_sample(d, Ld, K)
+            out.append(dict(config=3, workload="UCI gas stand-in (MNAR), REG_notMIWAE_v2 K=20, batch 128, p_missingness 50",
+                            dtype=prec, us_per_step=dt * 1e6, samples_per_s=128 / dt,
+                            roofline=dict(bound="mfma", achieved=f3 * 128 / dt / 1e12, peak=PEAK[prec], unit="TFLOP/s",
+                                          frac=f3 * 128 / dt / 1e12 / PEAK[prec], note="whole step")))
+            del tr, model
+        except Exception as e:
+            out.append(dict(config=3, dtype=prec, error=repr(e)[:200]))
+    # config 5: ONE acquisition step of active_learning_func (evaluate.py:394-440) on a Reg_VAE, n_test = 256, M = 50: the M
+    # Monte-Carlo forwards as one batched pass + the reward of every (row, candidate) + argmax
+    try:
+        n, M = 256, 50
+        torch.manual_seed(0)
+        model = vpc.Reg_VAE(d, 500, 10, Ld, TP, "bench", "kl_reg").to(dev)
+        xt, tm = x[:n], m[:n]
+        cur = (torch.rand(n, d, generator=torch.Generator().manual_seed(5)) < 0.3).float().to(dev)
+        cur[:, -1] = 0
+        from vpc_amd import active as act
+        with torch.no_grad():
+            def st5():
+                im = act.mc_forward(model, xt, cur, tm, M)
+                R = act.reward_matrix(model, xt, cur, im)
+                return R.argmax(1)
+            dt = timed_steps(st5, 30, 50)
+        enc_evals = 4 * (d - 1) * M * n  # encoder calls the reference makes for this step (evaluate.py:424-433, 514-634)
+        f5 = 2 * (d * 100 + 100 * 50 + 50 * 2 * Ld) * enc_evals
+        out.append(dict(config=5, workload="one active_learning_func acquisition step, Reg_VAE d=128, n_test=256, M=50",
+                        dtype="f32", ms_per_step=dt * 1e3, encoder_evaluations_replaced=enc_evals,
+                        roofline=dict(bound="mfma", achieved=f5 / dt / 1e12, peak=PEAK["f32"], unit="TFLOP/s",
+                                      frac=f5 / dt / 1e12 / PEAK["f32"],
+                                      note="priced at the reference's 4 (d-1) M n full encoder evaluations; the kernel "
+                                           "computes them as rank-1 updates of the first layer (DESIGN 2.4), so the "
+                                           "fraction is an equivalent rate, not pipe utilisation")))
+    except Exception as e:
+        out.append(dict(config=5, error=repr(e)[:200]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU (weak) / global rows (strong)")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--latent", type=int, default=10)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="which reading `value` reports; with more than one GPU both are measured and printed")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32",
+                    help="f32 = the headline (exact fp32 MFMA); bf16x3 / bf16 = extra lines on v_mfma_f32_16x16x32_bf16")
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the loop rotates over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs 2 / 3 / 5 lines (extra_configs)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the settle steps after the W warm-up steps")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=None)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up, count them through the collective and print {n_gpus}: launcher test")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # before anything in this process touches the GPU
+
+    import vpc_amd as vpc
+    rank, world, local = vpc.dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:  # launcher / rendezvous / rank count only (runs without a GPU over gloo: tests/test_bench_launch.py)
+        one = torch.ones(1)
+        if world > 1:
+            one = one.to(torch.device("cuda", local)) if torch.distributed.get_backend() == "nccl" else one
+            torch.distributed.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": int(one.item()), "world_size_env": world,
+                              "backend": torch.distributed.get_backend() if world > 1 else None}))
+        vpc.dp.shutdown()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    d, Ld = args.dim, args.latent
+
+    modes = [args.scaling] if world == 1 else [args.scaling, "strong" if args.scaling == "weak" else "weak"]
+    res = {mode: measure(vpc, args, rank, world, dev, mode) for mode in modes}
     if rank != 0:
         vpc.dp.shutdown()
         return
-    if not (total == total):
+    r = res[args.scaling]
+    if not (r["total"] == r["total"]):
         raise SystemExit("loss is NaN")
+    if r["seen"] != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the step's collective summed over {r['seen']} rank(s)")
 
-    ms_step = elapsed / args.steps * 1e3
-    value = Bg * args.steps / elapsed
+    B, Bg, ms_step, value, kern_ms, dom = r["B"], r["Bg"], r["ms_step"], r["value"], r["kern_ms"], r["dom"]
     fl = flops_per_sample(d, Ld)
-    kern_ms = {k: statistics.mean(a.elapsed_time(b) for a, b in v) for k, v in timers.items()}
-    dom = "decoder_fused"
     achieved = fl[dom] * B / (kern_ms[dom] * 1e-3) / 1e12
     rows = f"B={B} per GPU" if args.scaling == "weak" else f"global B={Bg} sharded {B} rows per GPU"
+    kname = {"decoder_fused": ("vpc::dec_kernel<8,true,FUSED,1> (small-batch shape)" if r["small"] else "vpc::dec8_kernel<8,true>")
+                              + " (vpc_decoder_fused)",
+             "step_fused": "vpc::step_bf16_kernel<8> (vpc_step_fused_bf16: encoder fwd + decoder + loss + all backward)"}[dom]
     out = {
         "metric": "training samples/sec (ELBO+consistency step), B=65536 d=128",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "samples/s", "n_gpus": r["seen"], "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
@@ -265,23 +456,28 @@ def main():
                                f"d={d}, L={Ld}, MCAR mask 0.7, p_missingness=30, Adam lr=1e-3, "
                                f"{args.batches} resident batches rotated",
                    "global_batch": Bg, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma",
-                     "kernel": ("vpc::dec_kernel<8,true,FUSED,1> (small-batch shape)" if tr.last_blocks[1] > (B + 127) // 128
-                                else "vpc::dec8_kernel<8,true>") + " (vpc_decoder_fused)",
+        "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
                      "frac": achieved / PEAK[args.precision],
-                     "traffic": measured_traffic(B, d, Ld, args.precision),
+                     "traffic": measured_traffic(B, d, Ld, args.precision, dom),
                      "flop_per_launch": fl[dom] * B, "avg_launch_ms": kern_ms[dom]},
         "kernels_ms": kern_ms,
         "step_hbm": (lambda tb: None if tb is None else {
             "bytes_per_step": tb, "achieved_TBps": tb / (ms_step * 1e-3) / 1e12, "peak_TBps": HBM_PEAK_TBS,
             "frac": tb / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
-            "compulsory_bytes_per_step": 768 * B})(measured_step_traffic(B, d, Ld, args.precision)),
+            "compulsory_bytes_per_step": 768 * B})(measured_step_traffic(B, d, Ld, args.precision, dom)),
         "step_tflops_algorithmic": fl["total"] * B * world / (ms_step * 1e-3) / 1e12,
-        "settle_steps": settle,
-        "per_step_sync_ms": per_step_sync_ms,
-        "loss_mean": total / args.steps,
+        "settle_steps": r["settle"],
+        "per_step_sync_ms": r["per_step_sync_ms"],
+        "loss_mean": r["total"] / args.steps,
     }
+    for mode in modes[1:] if world > 1 else []:
+        o = res[mode]
+        out[mode] = {"value": o["value"], "unit": "samples/s", "ms_per_step": o["ms_step"], "rows_per_gpu": o["B"],
+                     "global_batch": o["Bg"], "n_gpus": o["seen"], "kernels_ms": o["kern_ms"],
+                     "small_batch_shape": o["small"]}
+    if world == 1 and not args.no_extra_configs:
+        out["extra_configs"] = extra_configs(vpc, dev)
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(B, d, Ld, args.cpu_seconds, args.cpu_threads)
         out["cpu_baseline"] = cb

@@ -68,21 +68,69 @@ def nm_init_params(d: int, L: int, seed: int = 0) -> Dict[str, torch.Tensor]:
     return out
 
 
-class NMTorchPort:
-    """Functional restatement over a dict of tensors (keys NM_KEYS).  ``regularised`` selects REG_notMIWAE_v2."""
+def _bf16_t(t):
+    """tensor -> fp32 -> bf16 (round to nearest even) -> the tensor's dtype."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
 
-    def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool):
+
+def _split_t(t):
+    v = t.to(torch.float32)
+    hi = v.to(torch.bfloat16).to(torch.float32)
+    lo = (v - hi).to(torch.bfloat16).to(torch.float32)
+    return hi.to(t.dtype), lo.to(t.dtype)
+
+
+def _mm_mode(a, b, mode):
+    if mode == "bf16":
+        return _bf16_t(a) @ _bf16_t(b)
+    ah, al = _split_t(a)
+    bh, bl = _split_t(b)
+    return ah @ bh + ah @ bl + al @ bh
+
+
+class _RoundedLinear(torch.autograd.Function):
+    """nn.Linear as the generic GEMM kernels compute it with precision bf16 / bf16x3 (csrc/vpc_gemm.hip: fp32 tiles in LDS,
+    fragments converted in registers): both operands of EVERY product - forward x W^T, dgrad dY W, wgrad dY^T x - are
+    rounded to bf16 (or split hi + lo with the lo * lo term dropped), the bias is added and db is summed in fp32 from the
+    unrounded dY.  Run it on float64 tensors: the accumulation is then exact and only the operand rounding is modelled."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mode):
+        ctx.mode, ctx.shape = mode, x.shape
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w)
+        return (_mm_mode(x2, w.t(), mode) + b).reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = _mm_mode(dy2, w, ctx.mode).reshape(ctx.shape)
+        return dx, _mm_mode(dy2.t(), x2, ctx.mode), dy2.sum(0), None
+
+
+def rounded_linear(mode):
+    """F.linear replacement for NMTorchPort(linear=...): the bf16-emulating oracle of the MNAR step."""
+    return lambda x, w, b: _RoundedLinear.apply(x, w, b, mode)
+
+
+class NMTorchPort:
+    """Functional restatement over a dict of tensors (keys NM_KEYS).  ``regularised`` selects REG_notMIWAE_v2.
+    ``linear``: the affine layer (default F.linear; `rounded_linear("bf16")` models the bf16 GEMM kernels)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool, linear=None):
         self.p = params
         self.L, self.K, self.reg = L, K, regularised
+        self.lin = linear or F.linear
 
     # VAE.py:2378-2391 / :2749-2765
     def encoder(self, x, mask, eps: Optional[torch.Tensor]):
         p = self.p
         dt = p["seq_encoder.0.weight"].dtype  # fp32 in the reference (x.float()); float64 only in the oracle self-check
-        h = F.elu(F.linear(x.to(dt) * mask.to(dt), p["seq_encoder.0.weight"], p["seq_encoder.0.bias"]))
-        h = F.elu(F.linear(h, p["seq_encoder.2.weight"], p["seq_encoder.2.bias"]))
-        mean = F.linear(h, p["q_mu.0.weight"], p["q_mu.0.bias"])
-        logvar = F.linear(h, p["q_logstd.0.weight"], p["q_logstd.0.bias"])
+        h = F.elu(self.lin(x.to(dt) * mask.to(dt), p["seq_encoder.0.weight"], p["seq_encoder.0.bias"]))
+        h = F.elu(self.lin(h, p["seq_encoder.2.weight"], p["seq_encoder.2.bias"]))
+        mean = self.lin(h, p["q_mu.0.weight"], p["q_mu.0.bias"])
+        logvar = self.lin(h, p["q_logstd.0.weight"], p["q_logstd.0.bias"])
         mean = mean.unsqueeze(1).expand(-1, self.K, -1)
         logvar = logvar.unsqueeze(1).expand(-1, self.K, -1)
         z = mean if eps is None else mean + eps * torch.exp(logvar / 2)
@@ -91,10 +139,10 @@ class NMTorchPort:
     # VAE.py:2393-2397 / :2767-2772
     def decoder(self, z):
         p = self.p
-        g = F.elu(F.linear(z, p["seq_decoder.0.weight"], p["seq_decoder.0.bias"]))
-        g = F.elu(F.linear(g, p["seq_decoder.2.weight"], p["seq_decoder.2.bias"]))
-        xm = torch.sigmoid(F.linear(g, p["x_mean.0.weight"], p["x_mean.0.bias"]))
-        xl = F.hardtanh(F.linear(g, p["x_logvar.0.weight"], p["x_logvar.0.bias"]), -10.0, 0.0)
+        g = F.elu(self.lin(z, p["seq_decoder.0.weight"], p["seq_decoder.0.bias"]))
+        g = F.elu(self.lin(g, p["seq_decoder.2.weight"], p["seq_decoder.2.bias"]))
+        xm = torch.sigmoid(self.lin(g, p["x_mean.0.weight"], p["x_mean.0.bias"]))
+        xl = F.hardtanh(self.lin(g, p["x_logvar.0.weight"], p["x_logvar.0.bias"]), -10.0, 0.0)
         return xm, xl
 
     @staticmethod

@@ -311,16 +311,71 @@ class PassCache:
     xhat: np.ndarray
 
 
-def closed_form_pass(P, x, m, eps, L):
+# ---- bf16 emulation: the float64 closed form with every GEMM operand rounded exactly where the
+# bf16 kernels round it (csrc/vpc_bf16.h).  What the kernels do, restated:
+#   * a product's operands - activations, dY and the packed weight image - are bf16 (round to nearest even from the fp32
+#     value), accumulation and everything elementwise (bias of layer 1, ReLU, reparameterisation, sigmoid, loss, KL, seeds)
+#     stays fp32; "bf16x3" carries every operand as hi = bf16(v), lo = bf16(v - hi) and forms hi*hi + hi*lo + lo*hi
+#   * biases of layers 2..6 live in the weight image (a column that multiplies a constant-1 unit): they are rounded like
+#     weights, and their gradients are column sums of the ROUNDED dY (wgrad against the constant 1); b1 is added in fp32 and
+#     db1 is the fp32 sum of the unrounded dh1 (enc_bwd_kernel's dbacc)
+#   * a value is rounded once and that packed operand feeds the next layer, the dgrad and the wgrad alike
+def bf16_round(a):
+    """float -> fp32 -> bf16 (round to nearest even, as v_cvt_pk_bf16_f32) -> float64."""
+    u = np.ascontiguousarray(np.asarray(a, np.float32)).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(a))
+
+
+def bf16_split(a):
+    """hi = bf16(v), lo = bf16(v - hi) with v the fp32 value (pk_bf16 / pk_bf16_lo in vpc_bf16.h)."""
+    v = np.asarray(a, np.float32)
+    hi = bf16_round(v)
+    lo = bf16_round(v.astype(np.float64) - hi)  # v - hi is exact in fp32
+    return hi, lo
+
+
+class GemmModel:
+    """How a matrix product sees its operands: "f64" exact, "bf16" plain bf16 inputs, "bf16x3" split bf16."""
+
+    def __init__(self, mode="f64"):
+        if mode in ("f32", None):
+            mode = "f64"
+        assert mode in ("f64", "bf16", "bf16x3"), mode
+        self.mode = mode
+
+    def op(self, a):  # the value a product effectively multiplies with
+        if self.mode == "f64":
+            return np.asarray(a, np.float64)
+        if self.mode == "bf16":
+            return bf16_round(a)
+        hi, lo = bf16_split(a)
+        return hi + lo
+
+    def mm(self, a, b):
+        if self.mode == "f64":
+            return a @ b
+        if self.mode == "bf16":
+            return bf16_round(a) @ bf16_round(b)
+        ah, al = bf16_split(a)
+        bh, bl = bf16_split(b)
+        return ah @ bh + ah @ bl + al @ bh  # the lo * lo term is dropped (bf_mma)
+
+    def colsum(self, dy):  # bias gradient through the constant-1 column of a wgrad
+        return self.op(dy).sum(0)
+
+
+def closed_form_pass(P, x, m, eps, L, gm=None):
+    gm = gm or GemmModel()
     xin = x * m
-    h1 = np.maximum(xin @ P["seq_encoder.0.weight"].T + P["seq_encoder.0.bias"], 0)
-    h2 = np.maximum(h1 @ P["seq_encoder.2.weight"].T + P["seq_encoder.2.bias"], 0)
-    o = h2 @ P["seq_encoder.4.weight"].T + P["seq_encoder.4.bias"]
+    h1 = np.maximum(gm.mm(xin, P["seq_encoder.0.weight"].T) + P["seq_encoder.0.bias"], 0)
+    h2 = np.maximum(gm.mm(h1, P["seq_encoder.2.weight"].T) + gm.op(P["seq_encoder.2.bias"]), 0)
+    o = gm.mm(h2, P["seq_encoder.4.weight"].T) + gm.op(P["seq_encoder.4.bias"])
     mean, logvar = o[:, :L], o[:, L:]
     z = mean + eps * np.exp(logvar / 2)
-    g1 = np.maximum(z @ P["seq_decoder.0.weight"].T + P["seq_decoder.0.bias"], 0)
-    g2 = np.maximum(g1 @ P["seq_decoder.2.weight"].T + P["seq_decoder.2.bias"], 0)
-    xhat = 1.0 / (1.0 + np.exp(-(g2 @ P["seq_decoder.4.weight"].T + P["seq_decoder.4.bias"])))
+    g1 = np.maximum(gm.mm(z, P["seq_decoder.0.weight"].T) + gm.op(P["seq_decoder.0.bias"]), 0)
+    g2 = np.maximum(gm.mm(g1, P["seq_decoder.2.weight"].T) + gm.op(P["seq_decoder.2.bias"]), 0)
+    xhat = 1.0 / (1.0 + np.exp(-(gm.mm(g2, P["seq_decoder.4.weight"].T) + gm.op(P["seq_decoder.4.bias"]))))
     return PassCache(xin, h1, h2, mean, logvar, eps, z, g1, g2, xhat)
 
 
@@ -337,34 +392,37 @@ def _klr_np(mq, lq, mp, lp):
     return float(np.sum(0.5 * (np.exp(lq - lp) + (mq - mp) ** 2 * np.exp(-lp) - 1.0 - (lq - lp))))
 
 
-def _pass_backward(P, c: PassCache, dxhat, dmean, dlogvar, grads):
+def _pass_backward(P, c: PassCache, dxhat, dmean, dlogvar, grads, gm=None):
     """Backprop one encoder/decoder pass given seeds on xhat, mean, logvar; accumulates into grads."""
+    gm = gm or GemmModel()
     dpre3 = dxhat * c.xhat * (1 - c.xhat)
-    grads["seq_decoder.4.weight"] += dpre3.T @ c.g2
-    grads["seq_decoder.4.bias"] += dpre3.sum(0)
-    dg2 = (dpre3 @ P["seq_decoder.4.weight"]) * (c.g2 > 0)
-    grads["seq_decoder.2.weight"] += dg2.T @ c.g1
-    grads["seq_decoder.2.bias"] += dg2.sum(0)
-    dg1 = (dg2 @ P["seq_decoder.2.weight"]) * (c.g1 > 0)
-    grads["seq_decoder.0.weight"] += dg1.T @ c.z
-    grads["seq_decoder.0.bias"] += dg1.sum(0)
-    dz = dg1 @ P["seq_decoder.0.weight"]
+    grads["seq_decoder.4.weight"] += gm.mm(dpre3.T, c.g2)
+    grads["seq_decoder.4.bias"] += gm.colsum(dpre3)
+    dg2 = gm.mm(dpre3, P["seq_decoder.4.weight"]) * (c.g2 > 0)
+    grads["seq_decoder.2.weight"] += gm.mm(dg2.T, c.g1)
+    grads["seq_decoder.2.bias"] += gm.colsum(dg2)
+    dg1 = gm.mm(dg2, P["seq_decoder.2.weight"]) * (c.g1 > 0)
+    grads["seq_decoder.0.weight"] += gm.mm(dg1.T, c.z)
+    grads["seq_decoder.0.bias"] += gm.colsum(dg1)
+    dz = gm.mm(dg1, P["seq_decoder.0.weight"])
     dm = dmean + dz
     dl = dlogvar + dz * c.eps * 0.5 * np.exp(c.logvar / 2)
     do = np.concatenate([dm, dl], axis=1)
-    grads["seq_encoder.4.weight"] += do.T @ c.h2
-    grads["seq_encoder.4.bias"] += do.sum(0)
-    dh2 = (do @ P["seq_encoder.4.weight"]) * (c.h2 > 0)
-    grads["seq_encoder.2.weight"] += dh2.T @ c.h1
-    grads["seq_encoder.2.bias"] += dh2.sum(0)
-    dh1 = (dh2 @ P["seq_encoder.2.weight"]) * (c.h1 > 0)
-    grads["seq_encoder.0.weight"] += dh1.T @ c.xin
-    grads["seq_encoder.0.bias"] += dh1.sum(0)
+    grads["seq_encoder.4.weight"] += gm.mm(do.T, c.h2)
+    grads["seq_encoder.4.bias"] += gm.colsum(do)
+    dh2 = gm.mm(do, P["seq_encoder.4.weight"]) * (c.h2 > 0)
+    grads["seq_encoder.2.weight"] += gm.mm(dh2.T, c.h1)
+    grads["seq_encoder.2.bias"] += gm.colsum(dh2)
+    dh1 = gm.mm(dh2, P["seq_encoder.2.weight"]) * (c.h1 > 0)
+    grads["seq_encoder.0.weight"] += gm.mm(dh1.T, c.xin)
+    grads["seq_encoder.0.bias"] += dh1.sum(0)  # fp32 sum of the unrounded dh1 (explicit bias vector of layer 1)
 
 
 def closed_form_reg_step(params, L, x, mask, mask_p, eps_q, eps_p, *, alpha=1.0, beta=1.0,
-                         beta_annealing=False, epoch=1, reg_type="kl_reg", eps_ml=None):
-    """float64 loss + analytic grads of the Reg_VAE training loss (train stage). Appendix A."""
+                         beta_annealing=False, epoch=1, reg_type="kl_reg", eps_ml=None, gemm="f64"):
+    """float64 loss + analytic grads of the Reg_VAE training loss (train stage). Appendix A.
+    gemm = "bf16" / "bf16x3": matrix products with operands rounded where the bf16 kernels round them (GemmModel)."""
+    gm = GemmModel(gemm)
     P = _np(params)
     x = np.asarray(x, np.float64)
     M = np.asarray(mask, np.float64)
@@ -375,8 +433,8 @@ def closed_form_reg_step(params, L, x, mask, mask_p, eps_q, eps_p, *, alpha=1.0,
     B = x.shape[0]
     bw = (epoch / MAX_EPOCH) * beta if beta_annealing else beta
     s2 = math.exp(X_LOGVAR)
-    cq = closed_form_pass(P, x, M, eq, L)
-    cp = closed_form_pass(P, x, Pm, ep, L)
+    cq = closed_form_pass(P, x, M, eq, L, gm)
+    cp = closed_form_pass(P, x, Pm, ep, L, gm)
     RE_q, RE_p = _nll_np(x, cq.xhat, M), _nll_np(x, cp.xhat, Pm)
     KL_q, KL_p = _kl0_np(cq.mean, cq.logvar), _kl0_np(cp.mean, cp.logvar)
     loss_q, loss_p = RE_q + bw * KL_q, RE_p + bw * KL_p
@@ -410,24 +468,25 @@ def closed_form_reg_step(params, L, x, mask, mask_p, eps_q, eps_p, *, alpha=1.0,
         dlp = w * (0.5 - 0.5 * dlt ** 2 * eip)
     else:
         raise ValueError(reg_type)
-    _pass_backward(P, cq, dxq / B, dmq / B, dlq / B, grads)
-    _pass_backward(P, cp, dxp / B, dmp / B, dlp / B, grads)
+    _pass_backward(P, cq, dxq / B, dmq / B, dlq / B, grads, gm)
+    _pass_backward(P, cp, dxp / B, dmp / B, dlp / B, grads, gm)
     terms = dict(RE_q=RE_q, RE_p=RE_p, KL_q=KL_q, KL_p=KL_p)
     return loss / B, grads, (cq, cp), terms
 
 
-def closed_form_vanilla_step(params, L, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1):
+def closed_form_vanilla_step(params, L, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1, gemm="f64"):
+    gm = GemmModel(gemm)
     P = _np(params)
     x = np.asarray(x, np.float64)
     M = np.asarray(mask, np.float64)
     B = x.shape[0]
     bw = (epoch / MAX_EPOCH) * beta if beta_annealing else beta
     s2 = math.exp(X_LOGVAR)
-    cq = closed_form_pass(P, x, M, np.asarray(eps_q, np.float64), L)
+    cq = closed_form_pass(P, x, M, np.asarray(eps_q, np.float64), L, gm)
     loss = _nll_np(x, cq.xhat, M) + bw * _kl0_np(cq.mean, cq.logvar)
     grads = {k: np.zeros_like(v) for k, v in P.items()}
     _pass_backward(P, cq, M * (cq.xhat - x) / s2 / B, bw * cq.mean / B,
-                   bw * 0.5 * (np.exp(cq.logvar) - 1) / B, grads)
+                   bw * 0.5 * (np.exp(cq.logvar) - 1) / B, grads, gm)
     return loss / B, grads, cq
 
 

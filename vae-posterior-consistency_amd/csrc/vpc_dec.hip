@@ -757,6 +757,6 @@ extern "C" int vpc_decoder_fused(const float* x, const float* dec_img, int npass
         if (!ts.small && dt_for(d) == 8) return dec8_dispatch(a, vec, ts.grid_x, precision, (hipStream_t)stream);
         return dispatch_bf(a, ts, precision, (hipStream_t)stream);
     }
-    if (!ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, 0, (hipStream_t)stream);
+    if (vec && !ts.small && dt_for(d) == 8 && !(e8 && atoi(e8) == 0)) return dec8_dispatch(a, vec, ts.grid_x, 0, (hipStream_t)stream);
     return dispatch<MODE_FUSED>(a, vec, ts, (hipStream_t)stream);
 }

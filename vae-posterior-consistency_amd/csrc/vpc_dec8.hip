@@ -642,13 +642,14 @@ size_t dec8_lds(int DT, int prec) {
 int dec8_dispatch(const DecArgs& a, bool vec, int grid, int prec, hipStream_t s) {
     const int DT = dt_for(a.d);
     const size_t lds = dec8_lds(DT, prec);
-    if (prec != PREC_F32 && !vec) return VPC_ERR_SHAPE;  // the bf16 variants cover the vector layout (d % 4 == 0) only
+    // vector layout (d % 4 == 0, 16-byte aligned rows) only: the scalar-load instantiation of this kernel spilled 468 B
+    // per lane at 256 registers; such shapes run the 4-wave kernel of vpc_dec.hip, which has 512 (the caller falls back)
+    if (!vec) return VPC_ERR_SHAPE;
 #define VPC_CASE8(T)                                                                                         \
     case T: {                                                                                                \
         auto kern = prec == PREC_BF16X3 ? dec8_kernel<T, true, PREC_BF16X3>                                   \
                     : prec == PREC_BF16 ? dec8_kernel<T, true, PREC_BF16>                                     \
-                    : vec               ? dec8_kernel<T, true, PREC_F32>                                      \
-                                        : dec8_kernel<T, false, PREC_F32>;                                    \
+                                        : dec8_kernel<T, true, PREC_F32>;                                     \
         if (!lds_attr_done(reinterpret_cast<const void*>(kern), lds)) return VPC_ERR_HIP;                    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DEC8_THREADS), lds, s, a);                                 \
         return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;                                       \

@@ -3,17 +3,19 @@ src/experiment_main/train.py:53-117 for Reg_VAE / vanilla_VAE:
 
     mask_p draw -> forward (2 x encoder, 2 x decoder) -> loss -> zero_grad -> backward -> Adam -> loss accumulate
 
-as 7 kernel launches and no B x d intermediate:
+as 5 kernel launches (6 under data parallelism) and no B x d intermediate:
 
-    vpc_draw_mask            mask_p = mask & Bernoulli(1 - p_missingness/100)        (train.py:53-55)
-    vpc_fill_normal          eps_q, eps_p (, eps_ml)                                 (VAE.py:389-392)
+    vpc_draw_step            mask_p = mask & Bernoulli(1 - p_missingness/100) and eps_q, eps_p (, eps_ml), Philox
+                             counters keyed by the GLOBAL row                        (train.py:53-55, VAE.py:389-392)
     vpc_encoder_fwd          both passes, writes h1/h2 workspaces + mean/logvar      (VAE.py:387-395)
     vpc_decoder_fused        reparameterise + decoder + loss + seeds + decoder bwd   (VAE.py:397-467)
     vpc_encoder_bwd          encoder backward of both passes                         (train.py:115)
-    vpc_reduce_partials x2   per-workgroup partial blocks -> flat gradient (deterministic order)
-      [data parallel: ONE all-reduce of the flat bucket (grads + loss terms) goes here]
-    vpc_adam_step            flat Adam + re-pack of the weight images                (train.py:114-116)
-    vpc_loss_finalize        loss scalar + device-side epoch accumulator             (train.py:117, no host sync)
+    vpc_reduce_step_adam     per-workgroup partial blocks -> flat gradient (fixed order) + loss scalar + epoch
+                             accumulator + flat Adam + re-pack of the weight images  (train.py:114-117, no host sync)
+      data parallel / graph replay: vpc_reduce_step -> [ONE all-reduce of the flat bucket: grads + loss terms]
+                             -> vpc_adam_step
+    precision "bf16", obs_dim in (64, 128], throughput shape: encoder_fwd + decoder_fused + encoder_bwd are ONE launch,
+    vpc_step_fused_bf16 (csrc/vpc_step.hip) - h1 / h2 / latent statistics never leave the chip
 
 Gradients are those of the GLOBAL mean loss: seeds carry 1/B_global, so summing the flat bucket over ranks is
 exactly `train_loss = loss / x.shape[0]` (VAE.py:452) on the concatenated batch.
@@ -137,6 +139,10 @@ class FusedTrainer:
         self.timers.setdefault(name, []).append((e0, e1))
         return r
 
+    def dominant_launch(self):
+        """Name (as in `timers`) of the launch that carries most of the step's FLOPs in the shape last stepped."""
+        return "step_fused" if getattr(self, "_used_step_fused", False) else "decoder_fused"
+
     def coefficients(self, epoch, alpha, beta, beta_annealing):
         """Loss coefficients of the generic form in csrc/vpc_dec.hip (VAE.py:425-446 / 1183-1195)."""
         bw = (epoch / MAX_EPOCH) * beta if beta_annealing else beta
@@ -200,8 +206,8 @@ class FusedTrainer:
             off_m = self.rng_offset
             self.rng_offset += (Bg * dk + 7) // 8 + 1
             if draw_eps:
-                ops.draw_step(mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m,
-                              self.rng_offset, _state, row_lo * dk, eps_shard)
+                self._timed("draw_step", ops.draw_step, mask, self.mask_p_buf, 1.0 - p_missingness / 100.0, eps_view,
+                            self.seed, off_m, self.rng_offset, _state, row_lo * dk, eps_shard)
                 self.rng_offset += n_eps_groups
                 draw_eps = False
             else:
@@ -238,7 +244,7 @@ class FusedTrainer:
         self.last_blocks = (nbE, nbD)
         if update and not self.dp and _state is None:
             self.step_count += 1
-            ops.reduce_step_adam(self.partE, nbE, lay.enc_part, self.partD, nbD,
+            self._timed("reduce_step", ops.reduce_step_adam, self.partE, nbE, lay.enc_part, self.partD, nbD,
                         lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
                         cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
                         self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
