@@ -370,14 +370,17 @@ def extra_configs(vpc, dev):
                 return R.argmax(1)
             dt = timed_steps(st5, 30, 50)
         enc_evals = 4 * (d - 1) * M * n  # encoder calls the reference makes for this step (evaluate.py:424-433, 514-634)
-        f5 = 2 * (d * 100 + 100 * 50 + 50 * 2 * Ld) * enc_evals
+        # algorithmic FLOP of the formulation the kernel uses: per (row, candidate, sample) two encodings that
+        # differ from the row's base encoding by a rank-1 update of layer 1 (100 FMA) + layers 2, 3; per (row, sample) two
+        # candidate-independent full encodings
+        f5 = 2 * n * M * ((d - 1) * 2 * (100 + 100 * 50 + 50 * 2 * Ld) + 2 * (d * 100 + 100 * 50 + 50 * 2 * Ld))
         out.append(dict(config=5, workload="one active_learning_func acquisition step, Reg_VAE d=128, n_test=256, M=50",
                         dtype="f32", ms_per_step=dt * 1e3, encoder_evaluations_replaced=enc_evals,
                         roofline=dict(bound="mfma", achieved=f5 / dt / 1e12, peak=PEAK["f32"], unit="TFLOP/s",
                                       frac=f5 / dt / 1e12 / PEAK["f32"],
-                                      note="priced at the reference's 4 (d-1) M n full encoder evaluations; the kernel "
-                                           "computes them as rank-1 updates of the first layer (DESIGN 2.4), so the "
-                                           "fraction is an equivalent rate, not pipe utilisation")))
+                                      note="whole acquisition step (M batched forwards through the API path + reward kernels "
+                                           "+ argmax) priced at the FLOP of the rank-1 formulation the kernel computes, not "
+                                           "at the reference's 4 (d-1) M n full encoder calls")))
     except Exception as e:
         out.append(dict(config=5, error=repr(e)[:200]))
     return out

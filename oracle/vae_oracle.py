@@ -572,7 +572,7 @@ def reward_matrix(port: "TorchPort", x, mask, M, im):
     return R
 
 
-def active_learning_loop(x, M, forward_xmean, reward_fn):
+def active_learning_loop(x, M, forward_xmean, reward_fn, max_steps=None):
     """CPU restatement of the acquisition loop of active_learning_func (src/experiment_main/evaluate.py:352-456, one
     repeat, the non-flow branch): mask starts all-unobserved; per step M forward passes give the MC imputations `im`, the
     reward matrix R (evaluate.py:424-433 -> R_lindley_chain) picks argmax per row, the chosen feature is revealed and the
@@ -585,7 +585,7 @@ def active_learning_loop(x, M, forward_xmean, reward_fn):
     mse = lambda xm: torch.nn.functional.mse_loss(xm[:, -1], x[:, -1])  # noqa: E731  (evaluate.py:390)
     curve = [torch.stack([mse(forward_xmean(mask)) for _ in range(M)]).mean()]
     actions, R_hist, ims = [], [], []
-    for t in range(d - 1):
+    for t in range(d - 1 if max_steps is None else min(max_steps, d - 1)):
         im = torch.stack([forward_xmean(mask) for _ in range(M)], 0)
         R = reward_fn(x, mask, im)
         i_opt = R.argmax(1)

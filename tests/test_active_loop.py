@@ -106,3 +106,52 @@ def test_gpu_loop_with_device_side_draws(tmp_path, monkeypatch):
     curve = out["information_curve_CHAI"][:, 0].numpy()
     assert np.all(curve[:, -1] < 0.5 * curve[:, 0])
     assert np.all(np.abs(curve[:, -1] - g["info_curve"][-1]) < 0.3 * g["info_curve"][-1] + 5e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_loop_at_full_width_vs_oracle(tmp_path, monkeypatch):
+    """Config 5 at the width BASELINE names (d = 128): the first 3 acquisition steps of active_learning_func with n = 32 rows
+    and M = 8 Monte-Carlo passes, the forward passes REPLAYED into both loops (one seeded stream of decoder outputs), GPU
+    loop (vpc_reward_matrix: rank-1 first-layer updates on MFMA) against the oracle's restatement of
+    evaluate.py:394-440, 514-634 (pinned to the reference's own run at d = 14 above): every reward within 1e-4 of the
+    reward scale + fp32 round-off, identical acquisitions."""
+    monkeypatch.chdir(tmp_path)
+    d, L, n, M, steps = 128, 10, 32, 8, 3
+    g = torch.Generator().manual_seed(11)
+    base, mix = torch.rand(n + 4096, 4, generator=g), torch.rand(4, d, generator=g)
+    data = torch.sigmoid(3.0 * (base @ mix / mix.sum(0) - 0.5)) + 0.05 * torch.rand(n + 4096, d, generator=g)
+    data = (data - data.min(0).values) / (data.max(0).values - data.min(0).values)
+    torch.manual_seed(3)
+    m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": 64, "patience": 100}, "exp", "kl_reg").cuda()
+    tr = vpc.FusedTrainer(m)
+    xt, mt = data[n:].cuda(), (torch.rand(4096, d, generator=g) < 0.7).cuda()
+    for i in range(200):  # a briefly trained model: rewards of a random-init encoder are all round-off
+        tr.step(xt, mt, alpha=1.0, epoch=i + 1)
+    params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "prior" not in k}
+    port = O.TorchPort(params, L)
+    x, tmask = data[:n].clone(), torch.rand(n, d, generator=g) < 0.7
+
+    def replay(seed):  # one model.forward: x_mean_q of the oracle's port under a seeded eps stream
+        gg = torch.Generator().manual_seed(seed)
+
+        def fwd(mask):
+            eps = torch.randn(n, L, generator=gg)
+            with torch.no_grad():
+                z, _, _ = port.encoder(x, mask.cpu() > 0.5, eps=eps)
+                return port.decoder(z)[0]
+        return fwd
+
+    with torch.no_grad():
+        ref = O.active_learning_loop(x, M, replay(5), lambda xx, mm, im: O.reward_matrix(port, xx, mm, M, im), max_steps=steps)
+    out = vpc.active_learning_func(None, x, tmask, 30, d, 500, 10, M, L, "toy", {"batch_size": 64, "patience": 100}, "exp",
+                                   "reg_vae1", 100, 1, 1, alpha=1.0, p_missingness=30, reg_type="kl_reg", Repeat=1, model=m,
+                                   _forward=replay(5), max_steps=steps, save=False)
+    R, want = out["R_hist_CHAI"][0, :steps].numpy(), ref["R_hist"].numpy()
+    live = want != -1e4
+    scale = np.max(np.abs(want[live]))
+    assert scale > 1e-3  # the trained encoder does discriminate between candidates
+    assert np.array_equal(R == -1e4, ~live)
+    assert np.max(np.abs(R[live] - want[live])) <= 1e-4 * scale + 5e-7, (np.max(np.abs(R[live] - want[live])), scale)
+    assert np.array_equal(out["action_CHAI"][0, :, :steps].numpy(), ref["action"].numpy())
+    assert np.array_equal(out["im_CHAI"][0, :steps].numpy(), ref["im"].numpy())
+    assert np.allclose(out["information_curve_CHAI"][0, 0, :steps + 1].numpy(), ref["info_curve"].numpy(), rtol=1e-5, atol=1e-7)

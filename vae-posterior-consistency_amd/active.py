@@ -106,9 +106,9 @@ def active_learning_func(data_loader_train, test_data, test_mask, missing_rate, 
                          data_type, training_parameters, experiment_type, vae_type, max_epochs, valid_k, num_estimates,
                          device=None, alpha=1.0, stage="evaluate", p_missingness=30, reg_type="ml_reg", beta=1.0,
                          beta_annealing=False, alpha_annealing=True, Repeat=5, model=None, save=True, verbose=False,
-                         _forward=None):
+                         _forward=None, max_steps=None):
     """Active variable selection, src/experiment_main/evaluate.py:300-511 (same positional signature; `model`, `save`,
-    `verbose`, `_forward` are additions).  Per repeat: all features start unobserved (the target - last column - stays
+    `verbose`, `_forward`, `max_steps` (stop after that many acquisitions; the rest of the outputs stays zero) are additions).  Per repeat: all features start unobserved (the target - last column - stays
     unobserved throughout); at each of the obs_dim - 1 steps M Monte-Carlo forward passes impute the rows (`im`), the
     information reward of revealing each candidate feature is evaluated for every row - ONE vpc_reward_matrix call instead
     of the reference's (obs_dim - 1) R_lindley_chain calls with 4 M encoder passes each - the best candidate per row is
@@ -147,7 +147,7 @@ def active_learning_func(data_loader_train, test_data, test_mask, missing_rate, 
                 return ((xm[:, :, -1] - x[None, :, -1]) ** 2).mean(1).mean()
 
             info[r, :, 0] = target_mse(passes(mask)).cpu()
-            for t in range(d - 1):
+            for t in range(d - 1 if max_steps is None else min(max_steps, d - 1)):
                 if verbose:
                     print("Repeat = {:.1f}".format(r)); print("Strategy = {:.1f}".format(2)); print("Step = {:.1f}".format(t))
                 im = passes(mask)
