@@ -328,6 +328,28 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
                        const float* E, const float* tb, const float* Wp, float* scratch, long scratch_floats, float* gE,
                        float* gtb, float* gWp, float* gcp, int accumulate, long B, int d, int K, void* stream);
 
+/* ---- whole-step kernel, plain bf16 (csrc/vpc_step.hip): vpc_encoder_fwd + vpc_decoder_fused + vpc_encoder_bwd with
+ * precision 2 as ONE launch per 128-row tile - the step body of src/experiment_main/train.py:87-115 for Reg_VAE /
+ * vanilla_VAE (src/models/VAE.py:496-507 forward, :403-467 loss, autograd backward) with nothing but x, the masks and eps
+ * read from HBM and nothing but the gradient partial blocks and loss terms written.  obs_dim in (64, 128], obs_dim % 4 == 0,
+ * plain (not mask-augmented) encoder, any batch (the grid is min(tiles, CUs) workgroups looping over their tiles).
+ * Takes its own weight image (all six layers, bf16, 98.5 KB): vpc_step_layout_bf16 gives its size in floats and the
+ * kernel's dynamic-LDS bytes; vpc_step_build_indices_bf16 fills HOST arrays pack_idx_c[n_params] / img_template_c[floats];
+ * vpc_step_pack_weights_bf16 writes img_c from the flat parameters (after every optimiser step).
+ * vpc_step_fused_bf16: arguments as vpc_decoder_fused (mask[p] is the encoder mask AND the first loss mask of pass p;
+ * eps[p] [B][16] padded rows, eps_ml likewise); partE / partD / loss_partials are written in the layouts of
+ * vpc_encoder_bwd / vpc_decoder_fused (*nblocks_out blocks each), so vpc_reduce_step(_adam) consumes them unchanged. */
+/* 1 when the library runs a (B, d, L, npass) bf16 step through vpc_step_fused_bf16 (throughput workgroup shape), else 0 */
+int vpc_step_fused_applicable(long B, int d, int L, int npass);
+int vpc_step_layout_bf16(int d, int L, int* img_floats, int* lds_bytes);
+int vpc_step_build_indices_bf16(int d, int L, int* pack_idx_c, float* img_template_c);
+int vpc_step_pack_weights_bf16(const float* flat_params, const int* pack_idx_c, float* img_c, int n, void* stream);
+int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uint8_t* const* mask,
+                        const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
+                        const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar,
+                        float* partE, float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,11 +338,14 @@ def bf16_split(a):
 class GemmModel:
     """How a matrix product sees its operands: "f64" exact, "bf16" plain bf16 inputs, "bf16x3" split bf16."""
 
-    def __init__(self, mode="f64"):
+    def __init__(self, mode="f64", db1_rounded=False):
         if mode in ("f32", None):
             mode = "f64"
         assert mode in ("f64", "bf16", "bf16x3"), mode
         self.mode = mode
+        # the whole-step kernel (csrc/vpc_step.hip) takes db1 as a wgrad against a constant-1 operand, like the other
+        # biases: the sum of the ROUNDED dh1; the separate encoder-backward kernels sum the unrounded fp32 dh1
+        self.db1_rounded = db1_rounded
 
     def op(self, a):  # the value a product effectively multiplies with
         if self.mode == "f64":
@@ -415,14 +418,15 @@ def _pass_backward(P, c: PassCache, dxhat, dmean, dlogvar, grads, gm=None):
     grads["seq_encoder.2.bias"] += gm.colsum(dh2)
     dh1 = gm.mm(dh2, P["seq_encoder.2.weight"]) * (c.h1 > 0)
     grads["seq_encoder.0.weight"] += gm.mm(dh1.T, c.xin)
-    grads["seq_encoder.0.bias"] += dh1.sum(0)  # fp32 sum of the unrounded dh1 (explicit bias vector of layer 1)
+    # explicit bias vector of layer 1: fp32 sum of the unrounded dh1, or (whole-step kernel) a wgrad against ones
+    grads["seq_encoder.0.bias"] += gm.colsum(dh1) if gm.db1_rounded else dh1.sum(0)
 
 
 def closed_form_reg_step(params, L, x, mask, mask_p, eps_q, eps_p, *, alpha=1.0, beta=1.0,
-                         beta_annealing=False, epoch=1, reg_type="kl_reg", eps_ml=None, gemm="f64"):
+                         beta_annealing=False, epoch=1, reg_type="kl_reg", eps_ml=None, gemm="f64", db1_rounded=False):
     """float64 loss + analytic grads of the Reg_VAE training loss (train stage). Appendix A.
     gemm = "bf16" / "bf16x3": matrix products with operands rounded where the bf16 kernels round them (GemmModel)."""
-    gm = GemmModel(gemm)
+    gm = GemmModel(gemm, db1_rounded)
     P = _np(params)
     x = np.asarray(x, np.float64)
     M = np.asarray(mask, np.float64)
@@ -474,8 +478,9 @@ def closed_form_reg_step(params, L, x, mask, mask_p, eps_q, eps_p, *, alpha=1.0,
     return loss / B, grads, (cq, cp), terms
 
 
-def closed_form_vanilla_step(params, L, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1, gemm="f64"):
-    gm = GemmModel(gemm)
+def closed_form_vanilla_step(params, L, x, mask, eps_q, *, beta=1.0, beta_annealing=False, epoch=1, gemm="f64",
+                             db1_rounded=False):
+    gm = GemmModel(gemm, db1_rounded)
     P = _np(params)
     x = np.asarray(x, np.float64)
     M = np.asarray(mask, np.float64)

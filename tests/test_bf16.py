@@ -220,3 +220,28 @@ def test_mnar_trainer_vs_f32(prec, kind):
     tl, tg = TOL[prec]
     assert abs(res[prec][0] - res["f32"][0]) <= tl * abs(res["f32"][0]), (res[prec][0], res["f32"][0])
     assert rel(res[prec][1], res["f32"][1]) < tg
+
+
+def test_step_image_tables_cpu():
+    """Compact bf16 image of the whole-step kernel (csrc/vpc_step.hip): one u16 slot per parameter, no collisions, the
+    constants of the bias chain in place, size = 98.5 KB (no kernel launched)."""
+    import ctypes as C
+    l = vpc._lib.lib()
+    n, lds = C.c_int(), C.c_int()
+    assert l.vpc_step_layout_bf16(128, L, C.byref(n), C.byref(lds)) == 0
+    assert n.value * 4 == 100864 and lds.value <= 163840
+    lay = vpc._lib.layout(128, L)
+    idx = np.empty(lay.n_params, np.int32)
+    tmpl = np.empty(n.value, np.float32)
+    assert l.vpc_step_build_indices_bf16(128, L, idx.ctypes.data_as(C.c_void_p), tmpl.ctypes.data_as(C.c_void_p)) == 0
+    w = idx[idx >= 0]
+    assert len(np.unique(w)) == len(w) and w.max() < 2 * tmpl.size
+    b = -(idx[idx < 0] + 1)
+    assert len(b) == 100 and len(np.unique(b)) == 100  # the layer-1 bias stays fp32
+    assert not np.isin(w // 2, b).any()
+    u = tmpl.view(np.uint16)
+    ones = np.flatnonzero(u == 0x3F80)
+    assert len(ones) == 3 + 1 and not np.isin(ones, w).any()  # fake units of layers 2, 4, 5 + high half of the fp32 1.0 in b1
+    for bad in (64, 130, 126):
+        assert l.vpc_step_layout_bf16(bad, L, None, None) == 2
+    assert l.vpc_step_fused_applicable(100, 64, L, 2) == 0

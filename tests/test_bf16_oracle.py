@@ -119,7 +119,9 @@ def test_reg_step_on_reference_vectors(prec, tag, kw, tile, monkeypatch):
     tr.step(_t(g["x"]), _t(g["mask"]), _t(g["mask_p"]), _t(g["eps_q"]), _t(g["eps_p"]),
             _t(g["eps_ml"]) if tag == "ml" else None, update=False, **kw)
     loss, grads, _, _ = O.closed_form_reg_step(P, L, g["x"], g["mask"], g["mask_p"], g["eps_q"], g["eps_p"], reg_type=rt,
-                                               eps_ml=g["eps_ml"] if tag == "ml" else None, gemm=prec, **kw)
+                                               eps_ml=g["eps_ml"] if tag == "ml" else None, gemm=prec,
+                                               db1_rounded=tr._used_step_fused, **kw)
+    assert tr._used_step_fused == (prec == "bf16" and tile == "128")  # the whole-step kernel is what ran there
     _check(tr, m, loss, grads)
 
 
@@ -134,7 +136,9 @@ def test_vanilla_step_on_reference_vectors(prec, tile, monkeypatch):
     m = _model(vpc.vanilla_VAE, 128, P)
     tr = vpc.FusedTrainer(m, precision=prec)
     tr.step(_t(g["x"]), _t(g["mask"]), eps_q=_t(g["eps_q"]), update=False)
-    loss, grads, _ = O.closed_form_vanilla_step(P, L, g["x"], g["mask"], g["eps_q"], gemm=prec)
+    loss, grads, _ = O.closed_form_vanilla_step(P, L, g["x"], g["mask"], g["eps_q"], gemm=prec,
+                                                db1_rounded=tr._used_step_fused)
+    assert tr._used_step_fused == (prec == "bf16" and tile == "128")
     _check(tr, m, loss, grads)
 
 
@@ -157,7 +161,8 @@ def test_reg_step_ragged_shapes(prec, d, B, tile, monkeypatch):
     tr = vpc.FusedTrainer(m, precision=prec)
     tr.step(x.cuda(), mask.cuda(), mask_p.cuda(), eq.cuda(), ep.cuda(), alpha=0.8, beta=0.9, update=False)
     loss, grads, _, _ = O.closed_form_reg_step(P, L, x.numpy(), mask.numpy(), mask_p.numpy(), eq.numpy(), ep.numpy(),
-                                               alpha=0.8, beta=0.9, gemm=prec)
+                                               alpha=0.8, beta=0.9, gemm=prec, db1_rounded=tr._used_step_fused)
+    assert tr._used_step_fused == (prec == "bf16" and d > 64 and (tile == "128" or B > 16384))
     _check(tr, m, loss, grads)
 
 

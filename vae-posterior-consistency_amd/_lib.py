@@ -42,6 +42,11 @@ _PROTOS = {
     "vpc_layout_sizes_bf16": [I, I, I, IP, IP],
     "vpc_build_indices_bf16": [I, I, I, P, P],
     "vpc_pack_weights_bf16": [P, P, P, I, P],
+    "vpc_step_fused_applicable": [L_, I, I, I],
+    "vpc_step_layout_bf16": [I, I, IP, IP],
+    "vpc_step_build_indices_bf16": [I, I, P, P],
+    "vpc_step_pack_weights_bf16": [P, P, P, I, P],
+    "vpc_step_fused_bf16": [P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, P, F, F, F, F, F, F, P, P, P, IP, L_, I, I, P],
     "vpc_encoder_fwd": [P, P, I, PP, PP, PP, PP, PP, PP, PP, I, I, I, L_, I, I, P],
     "vpc_encoder_bwd": [P, P, I, PP, PP, PP, PP, PP, I, I, I, P, IP, L_, I, I, P],
     "vpc_decoder_fwd": [P, P, P, L_, I, I, P],
@@ -190,6 +195,21 @@ class Layout:
             check(l.vpc_build_indices_bf16(self.d, self.L, self.mask_augm, idx.ctypes.data_as(P), tmpl.ctypes.data_as(P)),
                   "vpc_build_indices_bf16")
             self._dev[key] = (torch.from_numpy(idx).to(device), tmpl, e.value)
+        return self._dev[key]
+
+    def step_tables(self, device):
+        """(pack_idx_c [n_params] int32 on `device`, img_template_c numpy [floats]) of the compact bf16 image of the
+        whole-step kernel (csrc/vpc_step.hip)."""
+        key = ("step", str(device))
+        if key not in self._dev:
+            l = lib()
+            n = C.c_int()
+            check(l.vpc_step_layout_bf16(self.d, self.L, C.byref(n), None), "vpc_step_layout_bf16")
+            idx = np.empty(self.n_params, np.int32)
+            tmpl = np.empty(n.value, np.float32)
+            check(l.vpc_step_build_indices_bf16(self.d, self.L, idx.ctypes.data_as(P), tmpl.ctypes.data_as(P)),
+                  "vpc_step_build_indices_bf16")
+            self._dev[key] = (torch.from_numpy(idx).to(device), tmpl)
         return self._dev[key]
 
     def inverse_maps(self, device):

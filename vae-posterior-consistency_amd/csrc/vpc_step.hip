@@ -1,0 +1,799 @@
+// Whole-step kernel, plain bf16 (gfx950): encoder forward + reparameterisation + decoder + ELBO / consistency loss + decoder
+// backward + encoder backward of BOTH passes of a Reg_VAE step (one pass for vanilla_VAE) in ONE launch per 128-row tile.
+//
+// Reference semantics: src/models/VAE.py:496-507 (forward: encoder -> decoder -> encoder -> decoder), :403-467 (loss), and
+// the autograd of src/experiment_main/train.py:115.  Same mathematics, loss coefficients (include/vpc.h), rounding points
+// (oracle/vae_oracle.py GemmModel "bf16") and partial-block layouts as vpc_encoder_fwd -> vpc_decoder_fused ->
+// vpc_encoder_bwd with precision = 2, which it replaces for obs_dim in (64, 128] in the throughput shape: what changes is
+// what crosses HBM.  The three-kernel form moves 633 MB per step at B = 65 536 (h1 / h2 round trip 212 MB, x and the masks
+// read by all three kernels, latent statistics and their seeds) against 50 MB of compulsory input; here a tile's x / mask
+// rows are read from HBM once (re-reads hit L2), h1 / h2 / mean / logvar / dmean / dlogvar never leave the chip, and the only
+// outputs are the two gradient partial blocks and the loss terms of the workgroup.
+//
+// LDS (162 304 of 163 840 bytes): ONE compact bf16 image of all six layers (98.5 KB: vpc_step_layout below - the pair-slot
+// image of vpc_bf16.h carries an unused lo half in plain bf16) + 15 staging slots of [128 rows x 16 features] bf16 for the
+// wgrad operands (bf_stage layout of vpc_bf16.h with FT = 15).
+// Registers (256 per wave, two waves per SIMD): 96 wgrad accumulators + 4 for db1, the latent statistics of both passes
+// (16), and per pass the packed h1 / h2 operands (24) across the decoder phase.  Pass p's statistics are needed by pass q's
+// KL(q || p) seeds before pass p runs, so the order is  E(p: statistics only) -> E(q) D(q) B(q) -> E(p) again, D(p), B(p):
+// three encoder forwards per tile instead of parking 24 registers per lane.
+// Staging rounds per pass (write - barrier - transposed reads + MFMA), slots in brackets:
+//   R1 dW6 = dpre^T g2 [0-7 | 8-14]   R2 dW5 = dg2^T g1 [0-6 | 8-11]   R3 dW4 = dg1^T z, dW3 = dml^T h2 [0-3, 4-5 | 8, 9-12]
+//   R4 dW2 = dh2^T h1 [0-3 | 8-14]    R5 dW1 = dh1^T (x*mask), db1 = dh1^T 1 [0-6 | 7-14]
+// (dz and the KL seeds need no barrier - dgrads read only the weight image - so dml is known before R3 is staged.)
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "vpc_bf16.h"
+#include "vpc_dec_args.h"
+#include <cstring>
+
+namespace vpc {
+
+// ------------------------------------------------------------------------------------------------ compact bf16 image
+// Layer image: `rows` rows of KP bf16 (KP = inputs padded to 32); the 16-byte slot pi = 4 kb + q of a row holds the k-slots
+// (kb, q, 0..7) = input features 32 kb + 16 (j >> 2) + 4 q + (j & 3) (vpc_bf16.h), pi XOR-swizzled with a key of the row.
+// The key makes the forward fragment read (ds_read_b128: 16 rows x one slot per lane group) conflict-free for every row
+// pitch - rows of 128 / 64 bytes share a 256-byte bank row in pairs / fours, so the key is taken from the row bits above
+// that - and, for 256-byte rows, spreads the 8 consecutive rows of a transposed read (ds_read_b64_tr_b16) over four slot
+// groups (2-way instead of 4-way conflicts).
+template <int KP>
+VPC_HD constexpr int c_key(int row) {
+    return KP == 128 ? ((((row >> 1) & 3) << 2) | (((row >> 3) & 1) << 1) | (row & 1))
+                     : ((row / (128 / KP)) & (KP / 8 - 1));
+}
+template <int KP>
+VPC_HD constexpr int c_elem(int row, int f) {  // u16 index of (row, input feature f) inside the layer image
+    return row * KP + (((4 * (f >> 5) + ((f >> 2) & 3)) ^ c_key<KP>(row)) << 3) + 4 * ((f >> 4) & 1) + (f & 3);
+}
+// dword offsets of the layers inside the image: [W1 112 x 128][b1 128 fp32][W2 64 x 128][W3 32 x 64][W4 64 x 32][W5 112 x 64]
+// [W6 128 x 128]
+struct StepImg {
+    static constexpr int oW1 = 0, ob1 = oW1 + H1P * 64, oW2 = ob1 + 128, oW3 = oW2 + H2P * 64, oW4 = oW3 + 32 * 32,
+                         oW5 = oW4 + H2P * 16, oW6 = oW5 + H1P * 32, total = oW6 + 128 * 64;
+};
+constexpr int ST_FT = 15;                              // staging slots (16-feature tiles) per row
+constexpr int ST_DW = (TILE_ROWS / 8) * ST_FT * 64;    // 15 360 dwords
+constexpr int STEP_LDS = (StepImg::total + ST_DW + WAVES * LOSS_TERMS) * 4;
+static_assert(STEP_LDS <= 163840, "LDS budget");
+
+typedef bf16x8 Op;  // one MFMA operand: 8 k-slots per lane
+
+__device__ __forceinline__ Op pack2(f32x4 t0, f32x4 t1) {
+    const u32x4 h = {pk_bf16(t0[0], t0[1]), pk_bf16(t0[2], t0[3]), pk_bf16(t1[0], t1[1]), pk_bf16(t1[2], t1[3])};
+    return __builtin_bit_cast(Op, h);
+}
+// forward A fragment: weight rows 16 mt + m, k-block kb
+template <int KP>
+__device__ __forceinline__ Op c_wfrag(const float* W, int mt, int kb, int m, int q) {
+    return __builtin_bit_cast(Op, *reinterpret_cast<const f32x4*>(W + (16 * mt + m) * (KP / 2) + 4 * ((4 * kb + q) ^ c_key<KP>(m))));
+}
+// transposed A fragment (dgrad): in-feature tile mt, k-block kb of the layer's OUT features (rows of the image)
+template <int KP, bool SECOND>
+__device__ __forceinline__ Op c_wfrag_T(const float* W, int mt, int kb, int lane) {
+    const int q = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 32 * kb + 4 * q + rr, r1 = r0 + 16;
+    const int pi = 4 * (mt >> 1) + pp, e = 2 * (mt & 1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 zz = {0, 0, 0, 0};
+    const s16x4 h0 = ds_tr16(W + r0 * (KP / 2) + 4 * (pi ^ c_key<KP>(r0)) + e);
+    const s16x4 h1 = SECOND ? ds_tr16(W + r1 * (KP / 2) + 4 * (pi ^ c_key<KP>(r1)) + e) : zz;
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    return __builtin_bit_cast(Op, h);
+}
+// forward layer: NT out tiles, KB k-blocks, fragments of tile mt + 1 requested before the MFMAs of tile mt
+template <int KP, int KB, int NT, typename F>
+__device__ __forceinline__ void c_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink) {
+    Op cur[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, 0, kb, m, q);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        Op nxt[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) nxt[kb] = c_wfrag<KP>(W, mt + 1 < NT ? mt + 1 : mt, kb, m, q);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = VPC_MFMA_BF(cur[kb], in[kb], acc);
+        sink(mt, acc);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+    }
+}
+// dgrad layer: NT in-feature tiles, KB k-blocks over the image's ROWT 16-row tiles
+template <int KP, int KB, int NT, int ROWT, typename F>
+__device__ __forceinline__ void c_layer_T(const float* W, const Op (&in)[KB], int lane, F&& sink) {
+    auto frag = [&](int mt, int kb) {
+        return (2 * kb + 1 < ROWT) ? c_wfrag_T<KP, true>(W, mt, kb, lane) : c_wfrag_T<KP, false>(W, mt, kb, lane);
+    };
+    Op cur[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) cur[kb] = frag(0, kb);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        Op nxt[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) nxt[kb] = frag(mt + 1 < NT ? mt + 1 : mt, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = VPC_MFMA_BF(cur[kb], in[kb], acc);
+        sink(mt, acc);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+    }
+}
+// ---- staging (bf_stage layout of vpc_bf16.h, FT = 15): operand of NT tiles whose first tile sits in slot `slot0`
+template <int NT>
+__device__ __forceinline__ void st_op(float* st, int row, int slot0, int kb, int q, Op op) {
+    const u32x4 h = __builtin_bit_cast(u32x4, op);
+    const int o0 = bf_stage_off<ST_FT>(row, slot0 + 2 * kb, q);
+    *reinterpret_cast<u32x2*>(st + o0) = u32x2{h[0], h[1]};
+    if (2 * kb + 1 < NT) *reinterpret_cast<u32x2*>(st + o0 + 64) = u32x2{h[2], h[3]};
+}
+__device__ __forceinline__ Op st_frag(const float* st, int slot, int kb, int lane) {
+    const int g = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int off = bf_stage_off<ST_FT>(32 * kb + 4 * g + rr, slot, pp);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * ST_FT);
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    return __builtin_bit_cast(Op, h);
+}
+
+struct StepArgs {
+    const float* x;
+    const float* img;
+    const uint8_t* m[2];    // encoder mask of pass p = first loss mask mA[p]
+    const uint8_t* mB[2];   // optional second loss mask: mE = mA * (1 - mB)
+    float cA[2], cE[2];
+    const float* eps[2];
+    const float* eps_ml;
+    float* partE;
+    float* partD;
+    double* loss_part;
+    float bq, bp, cr, wml, inv_B, x_logvar;
+    long B;
+    int d, L, npass, ntiles;
+    int dbg;  // diagnostic build only (-DVPC_ABLATE): 64 = print the phase stamps of workgroup 100
+};
+
+#ifdef VPC_ABLATE
+#define STP(i) VPC_STAMP(i)
+#else
+#define STP(i) do {} while (0)
+#endif
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VPC_ABLATE
+    unsigned long long T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    const float* W1 = lds + StepImg::oW1;
+    const float* b1 = lds + StepImg::ob1;
+    const float* W2 = lds + StepImg::oW2;
+    const float* W3 = lds + StepImg::oW3;
+    const float* W4 = lds + StepImg::oW4;
+    const float* W5 = lds + StepImg::oW5;
+    const float* W6 = lds + StepImg::oW6;
+    float* st = lds + StepImg::total;
+    float* red = st + ST_DW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int lrow = w * 16 + c;
+    const bool two = a.npass == 2;
+
+    // ---- x / mask rows of one tile in C layout (range-checked: rows past B read 0; columns past d read column 0 and are
+    // cleared through the mask word)
+    const int cq = (4 * q + 3 < a.d) ? 4 * q : 0;
+    const int vo = lrow * a.d + cq;
+    auto col_off = [&](int t) { return (t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0; };
+    auto mask_rsrc = [&](const uint8_t* mp, long row0) {
+        const long rem = (a.B - row0) * (long)a.d;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mp) + row0 * a.d, 0,
+                                                 rem > 0xffffffffL ? 0xffffffffu : (uint32_t)rem, 0x00020000);
+    };
+    load_image<13>(lds, a.img, StepImg::total);
+    __syncthreads();
+    STP(0);
+
+    f32x4 acc6[H1T], acc5[H2T], acc4 = zero4(), acc1[H1T], acc2[H2T], acc3 = zero4(), accb = zero4();
+#pragma unroll
+    for (int t = 0; t < H1T; ++t) { acc6[t] = zero4(); acc1[t] = zero4(); }
+#pragma unroll
+    for (int t = 0; t < H2T; ++t) { acc5[t] = zero4(); acc2[t] = zero4(); }
+    float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
+    const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
+    constexpr float HL2PI = 0.91893853320467274f;
+    const bool own6 = w < DT, own2 = w < H1T, own4 = w < H2T;
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const Op ones = __builtin_bit_cast(Op, ones_u);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * TILE_ROWS;
+        const bool ok = row0 + lrow < a.B;
+        const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
+        auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
+            return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
+        };
+        f32x4 muQ = zero4(), lvQ = zero4(), muP = zero4(), lvP = zero4();
+        // stage s: 0 = statistics of pass 1 only (two-pass models), 1 = pass 0, 2 = pass 1
+        for (int s = two ? 0 : 1; s <= a.npass; ++s) {
+            const int p = s == 0 ? 1 : s - 1;
+            asm volatile("" ::: "memory");  // the weight image never changes: keep LDS weight reads inside the stage
+            int cc = c, qq = q;
+            launder(cc, qq);
+            const __amdgpu_buffer_rsrc_t rmA = mask_rsrc(a.m[p], row0);
+            // ================================================================ E: encoder forward
+            Op h1b[4], h2b[2];
+            f32x4 mu, lv;
+            {
+                f32x4 xin[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const f32x4 xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(t)), 0, 0));
+                    const uint32_t mw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(t), 0, 0);
+                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
+                    xin[t] = xr * mask_to_f32(mw & vm);  // x.float() * mask  (VAE.py:388)
+                }
+                Op xb[(DT + 1) / 2];
+#pragma unroll
+                for (int kb = 0; kb < (DT + 1) / 2; ++kb) xb[kb] = pack2(xin[2 * kb], 2 * kb + 1 < DT ? xin[2 * kb + 1] : zero4());
+                f32x4 hprev = zero4();
+                c_layer_fwd<128, (DT + 1) / 2, H1T>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
+                    const f32x4 h = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
+                    if (mt & 1) h1b[mt >> 1] = pack2(hprev, h);
+                    else if (mt + 1 == H1T) h1b[mt >> 1] = pack2(h, zero4());
+                    hprev = h;
+                });
+                launder(cc, qq);
+                c_layer_fwd<128, 4, H2T>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
+                    const f32x4 h = relu4(acc);
+                    if (mt & 1) h2b[mt >> 1] = pack2(hprev, h);
+                    hprev = h;
+                });
+                f32x4 ml[2];
+                c_layer_fwd<64, 2, 2>(W3, h2b, cc, qq, [&](int mt, f32x4 acc) { ml[mt] = acc; });
+                const uint32_t okm = opaque_mask(ok);  // rows past B: statistics 0 (as the range-checked workspace loads gave)
+                mu = and4(ml[0], okm);
+                lv = and4(ml[1], okm);
+            }
+            if (p == 0) { muQ = mu; lvQ = lv; } else { muP = mu; lvP = lv; }
+            STP(1);
+            if (s == 0) continue;
+            const f32x4 mo = p == 0 ? muP : muQ, lo = p == 0 ? lvP : lvQ;  // the other pass's statistics
+            // ================================================================ D: reparameterise, decoder, loss, decoder backward
+            const f32x4 e = ld_lat(a.eps[p]);
+            f32x4 z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = mu[j] + ((4 * q + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
+            const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
+            f32x4 dz = zero4();
+            Op zb;
+            Op dmlb;  // packed (dmean | dlogvar) of this pass
+            VPC_CUT();
+            if (!skip_dec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * q + j == a.L) z[j] = 1.f;  // constant feature that drives the bias chain
+                zb = pack2(z, zero4());
+                Op g1b[2], g2b[4];
+                uint32_t gm1 = 0, gm2 = 0;
+                {
+                    f32x4 hprev = zero4();
+                    const Op zin[1] = {zb};
+                    c_layer_fwd<32, 1, H2T>(W4, zin, cc, qq, [&](int mt, f32x4 acc) {
+                        const f32x4 h = relu4(acc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gm1 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
+                        if (mt & 1) g1b[mt >> 1] = pack2(hprev, h);
+                        hprev = h;
+                    });
+                    launder(cc, qq);
+                    c_layer_fwd<64, 2, H1T>(W5, g1b, cc, qq, [&](int mt, f32x4 acc) {
+                        const f32x4 h = relu4(acc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gm2 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
+                        if (mt & 1) g2b[mt >> 1] = pack2(hprev, h);
+                        else if (mt + 1 == H1T) g2b[mt >> 1] = pack2(h, zero4());
+                        hprev = h;
+                    });
+                }
+                launder(cc, qq);
+                STP(2);
+                VPC_CUT();
+                // ---------------- output tiles: forward, loss terms, d / d pre-activation
+                Op dpreb[(DT + 1) / 2];
+                {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    constexpr float NLOG2E = -1.4426950408889634f;
+                    f32x2 sa2 = {0.f, 0.f}, se2 = {0.f, 0.f};
+                    const bool hasB = a.mB[p] != nullptr;
+                    const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
+                    const __amdgpu_buffer_rsrc_t rmB = mask_rsrc(hasB ? a.mB[p] : a.m[p], row0);
+                    auto fetch = [&](int mt, f32x4& xv, uint32_t& ua, uint32_t& ub) {
+                        xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(mt)), 0, 0));
+                        ua = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(mt), 0, 0);
+                        ub = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmB, vo + col_off(mt), 0, 0);
+                    };
+                    f32x4 xv_n, dprev = zero4();
+                    uint32_t ua_n, ub_n;
+                    fetch(0, xv_n, ua_n, ub_n);
+                    Op w6n[4];
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) w6n[kb] = c_wfrag<128>(W6, 0, kb, cc, qq);
+#pragma unroll
+                    for (int mt = 0; mt < DT; ++mt) {
+                        VPC_CUT();
+                        const f32x4 xv = xv_n;
+                        uint32_t ua = ua_n, ub = ub_n;
+                        if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
+                        Op w6c[4];
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) w6c[kb] = w6n[kb];
+                        if (mt + 1 < DT) {
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) w6n[kb] = c_wfrag<128>(W6, mt + 1, kb, cc, qq);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 pre = zero4();
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) pre = VPC_MFMA_BF(w6c[kb], g2b[kb], pre);
+                        if (mt >= DT / 2) {
+                            const uint32_t vm = opaque_mask(16 * mt + 4 * q + 3 < a.d);
+                            ua &= vm;
+                            ub &= vm;
+                        }
+                        const f32x4 mA = mask_to_f32(ua);
+                        const f32x4 mE = mA * (1.f - mask_to_f32(ub));  // no second mask: ub aliases ua, mA (1 - mA) = 0
+                        f32x4 dp4;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x2 p2 = {pre[2 * h], pre[2 * h + 1]}, x2 = {xv[2 * h], xv[2 * h + 1]};
+                            const f32x2 a2 = {mA[2 * h], mA[2 * h + 1]}, e2 = {mE[2 * h], mE[2 * h + 1]};
+                            const f32x2 en = p2 * NLOG2E;
+                            const f32x2 den = f32x2{__builtin_amdgcn_exp2f(en[0]), __builtin_amdgcn_exp2f(en[1])} + 1.f;
+                            const f32x2 xh = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                            const f32x2 diff = xh - x2;
+                            const f32x2 t = __builtin_elementwise_fma(diff * diff, f32x2{hinv_s2, hinv_s2}, f32x2{half_lv, half_lv});
+                            sa2 = __builtin_elementwise_fma(a2, t, sa2);
+                            se2 = __builtin_elementwise_fma(e2, t, se2);
+                            const f32x2 wgt = __builtin_elementwise_fma(f32x2{kE, kE}, e2, a2 * kA);
+                            const f32x2 dp = (wgt * diff) * __builtin_elementwise_fma(-xh, xh, xh);
+                            dp4[2 * h] = dp[0];
+                            dp4[2 * h + 1] = dp[1];
+                        }
+                        asm volatile("" : "+v"(dp4[0]), "+v"(dp4[1]), "+v"(dp4[2]), "+v"(dp4[3]), "+v"(sa2), "+v"(se2));
+                        if (mt & 1) dpreb[mt >> 1] = pack2(dprev, dp4);
+                        else if (mt + 1 == DT) dpreb[mt >> 1] = pack2(dp4, zero4());
+                        dprev = dp4;
+                    }
+                    const float sa = sa2[0] + sa2[1], se = se2[0] + se2[1];
+                    if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
+                }
+                STP(3);
+                VPC_CUT();
+                launder(cc, qq);
+                // ---------------- R1: dW6~ += dpre^T g2   (owner: wave w -> out tile w, all 7 in tiles)
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < (DT + 1) / 2; ++kb) st_op<DT>(st, lrow, 0, kb, qq, dpreb[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, g2b[kb]);
+                __syncthreads();
+                if (own6) {
+#pragma unroll
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const Op fa = st_frag(st, w, kb, 16 * qq + cc);
+                        Op fb = st_frag(st, 8, kb, 16 * qq + cc);
+#pragma unroll
+                        for (int nt = 0; nt < H1T; ++nt) {
+                            const Op fn = st_frag(st, 8 + (nt + 1 < H1T ? nt + 1 : nt), kb, 16 * qq + cc);
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc6[nt] = VPC_MFMA_BF(fa, fb, acc6[nt]);
+                            fb = fn;
+                        }
+                    }
+                }
+                STP(4);
+                VPC_CUT();
+                launder(cc, qq);
+                // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
+                Op dg2b[4];
+                {
+                    f32x4 hprev = zero4();
+                    c_layer_T<128, (DT + 1) / 2, H1T, DT>(W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                        const f32x4 h = gate_bits(acc, gm2, mt);
+                        if (mt & 1) dg2b[mt >> 1] = pack2(hprev, h);
+                        else if (mt + 1 == H1T) dg2b[mt >> 1] = pack2(h, zero4());
+                        hprev = h;
+                    });
+                }
+                STP(5);
+                VPC_CUT();
+                launder(cc, qq);
+                // ---------------- R2: dW5~ += dg2^T g1   (owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3)
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dg2b[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 8, kb, qq, g1b[kb]);
+                __syncthreads();
+                {
+                    const int nt5 = w & 3, mt5 = 4 * (w >> 2);
+#pragma unroll
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const Op fb = st_frag(st, 8 + nt5, kb, 16 * qq + cc);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i < 3 || w < 4) {
+                                const Op fa = st_frag(st, mt5 + i, kb, 16 * qq + cc);
+                                acc5[i] = VPC_MFMA_BF(fa, fb, acc5[i]);
+                            }
+                        }
+                    }
+                }
+                STP(6);
+                VPC_CUT();
+                launder(cc, qq);
+                // ---------------- dg1 = relu'(g1) * (W5~^T dg2);  dz = W4~^T dg1
+                Op dg1b[2];
+                {
+                    f32x4 hprev = zero4();
+                    c_layer_T<64, 4, H2T, H1T>(W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                        const f32x4 h = gate_bits(acc, gm1, mt);
+                        if (mt & 1) dg1b[mt >> 1] = pack2(hprev, h);
+                        hprev = h;
+                    });
+                    c_layer_T<32, 2, 1, H2T>(W4, dg1b, 16 * qq + cc, [&](int, f32x4 acc) { dz = acc; });
+                }
+                // R3's A operands of this pass (B operands and dml follow below, after the seeds)
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dg1b[kb]);
+                st_op<1>(st, lrow, 8, 0, qq, zb);
+            } else {
+                __syncthreads();
+            }
+            STP(7);
+            // ================================================================ KL terms, their seeds, total seeds on (mean | logvar)
+            {
+                f32x4 dmu, dlv;
+                const float b0 = (p == 0) ? a.bq : a.bp;
+                const float sgn = (p == 0) ? 1.f : -1.f;
+                const float crr = two ? a.cr : 0.f;
+                float kl0 = 0.f, klr = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float elv = __expf(lv[j]);
+                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
+                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
+                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
+                    const float dl = b0 * 0.5f * (elv - 1.f) + crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
+                    dmu[j] = dm * a.inv_B;
+                    dlv[j] = dl * a.inv_B;
+                }
+                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
+                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+                    const f32x4 e3 = ld_lat(a.eps_ml);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = ok && 4 * q + j < a.L;
+                        const float e3j = (4 * q + j < a.L) ? e3[j] : 0.f;
+                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
+                        const float dlt = mq + e3j * sq - mp;
+                        const float g = a.wml * dlt * eip * a.inv_B;
+                        if (p == 0) {
+                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                            dmu[j] += g;
+                            dlv[j] += g * e3j * 0.5f * sq;
+                        } else {
+                            dmu[j] -= g;
+                            dlv[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
+                        }
+                    }
+                }
+                if (!skip_dec) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ef = (4 * q + j < a.L) ? e[j] * 0.5f * __expf(0.5f * lv[j]) : 0.f;
+                        dmu[j] += dz[j];
+                        dlv[j] += dz[j] * ef;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // columns >= L of the latent tiles carry no gradient (dz's column L is db4)
+                    dmu[j] = (4 * q + j < a.L) ? dmu[j] : 0.f;
+                    dlv[j] = (4 * q + j < a.L) ? dlv[j] : 0.f;
+                }
+                dmlb = pack2(dmu, dlv);
+            }
+            // ================================================================ B: encoder backward
+            launder(cc, qq);
+            // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w),  dW3~ += dml^T h2 (wave w -> out tile w >> 2,
+            // in tile w & 3)
+            st_op<2>(st, lrow, 4, 0, qq, dmlb);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 9, kb, qq, h2b[kb]);
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                if (own4 && !skip_dec) {
+                    const Op fa = st_frag(st, w, kb, 16 * qq + cc);
+                    const Op fb = st_frag(st, 8, kb, 16 * qq + cc);
+                    acc4 = VPC_MFMA_BF(fa, fb, acc4);
+                }
+                const Op fa3 = st_frag(st, 4 + (w >> 2), kb, 16 * qq + cc);
+                const Op fb3 = st_frag(st, 9 + (w & 3), kb, 16 * qq + cc);
+                acc3 = VPC_MFMA_BF(fa3, fb3, acc3);
+            }
+            STP(8);
+            VPC_CUT();
+            launder(cc, qq);
+            // ---------------- dh2 = relu'(h2) * (W3~^T dml)
+            Op dh2b[2];
+            {
+                f32x4 hprev = zero4();
+                const Op din[1] = {dmlb};
+                c_layer_T<64, 1, H2T, 2>(W3, din, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                    const BfOp hp = {h2b[mt >> 1], h2b[mt >> 1]};
+                    const f32x4 h = bf_gate(acc, hp, mt & 1);
+                    if (mt & 1) dh2b[mt >> 1] = pack2(hprev, h);
+                    hprev = h;
+                });
+            }
+            // ---------------- R4: dW2~ += dh2^T h1   (owner: wave w < 7 -> in tile w, all 4 out tiles)
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dh2b[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, h1b[kb]);
+            __syncthreads();
+            if (own2) {
+#pragma unroll
+                for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                    asm volatile("" ::: "memory");
+                    const Op fb = st_frag(st, 8 + w, kb, 16 * qq + cc);
+#pragma unroll
+                    for (int mt = 0; mt < H2T; ++mt) {
+                        const Op fa = st_frag(st, mt, kb, 16 * qq + cc);
+                        acc2[mt] = VPC_MFMA_BF(fa, fb, acc2[mt]);
+                    }
+                }
+            }
+            STP(9);
+            VPC_CUT();
+            launder(cc, qq);
+            // ---------------- dh1 = relu'(h1) * (W2~^T dh2)
+            Op dh1b[4];
+            {
+                f32x4 hprev = zero4();
+                c_layer_T<128, 2, H1T, H2T>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                    const BfOp hp = {h1b[mt >> 1], h1b[mt >> 1]};
+                    const f32x4 h = bf_gate(acc, hp, mt & 1);
+                    if (mt & 1) dh1b[mt >> 1] = pack2(hprev, h);
+                    else if (mt + 1 == H1T) dh1b[mt >> 1] = pack2(h, zero4());
+                    hprev = h;
+                });
+            }
+            // ---------------- R5: dW1 += dh1^T (x * mask)  (owner: wave w -> in tile w, all 7 out tiles);  db1 += dh1^T 1
+            // (wave w < 7 -> out tile w).  x * mask is read again (L2) and staged by the owner of the row.
+            Op xb[(DT + 1) / 2];
+            {
+                f32x4 xprev = zero4();
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const f32x4 xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(t)), 0, 0));
+                    const uint32_t mw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(t), 0, 0);
+                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
+                    const f32x4 xi = xr * mask_to_f32(mw & vm);
+                    if (t & 1) xb[t >> 1] = pack2(xprev, xi);
+                    else if (t + 1 == DT) xb[t >> 1] = pack2(xi, zero4());
+                    xprev = xi;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dh1b[kb]);
+#pragma unroll
+            for (int kb = 0; kb < (DT + 1) / 2; ++kb) st_op<DT>(st, lrow, 7, kb, qq, xb[kb]);
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                asm volatile("" ::: "memory");
+                if (own2) accb = VPC_MFMA_BF(st_frag(st, w, kb, 16 * qq + cc), ones, accb);
+                if (own6) {
+                    const Op fb = st_frag(st, 7 + w, kb, 16 * qq + cc);
+                    Op fa = st_frag(st, 0, kb, 16 * qq + cc);
+#pragma unroll
+                    for (int mt = 0; mt < H1T; ++mt) {
+                        const Op fn = st_frag(st, mt + 1 < H1T ? mt + 1 : mt, kb, 16 * qq + cc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc1[mt] = VPC_MFMA_BF(fa, fb, acc1[mt]);
+                        fa = fn;
+                    }
+                }
+            }
+            STP(10);
+        }
+    }
+    // ================================================================ partial blocks (layouts of vpc_layout.h) and loss terms
+    {
+        float* part = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < H1T; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = own6 ? acc1[mt][j] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = own2 ? acc2[mt][j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
+        // db1[16 w + 4 q + j]: every column of the ones product holds the sum; lane c == 0 writes it
+        if (c == 0 && own2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 16 * w + 4 * q + j] = accb[j];
+        }
+        if (w == 7 && lane < 16) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 112 + lane] = 0.f;
+    }
+    {
+        float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
+        const int hi = w >> 2;
+#pragma unroll
+        for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = own6 ? acc6[nt][j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
+        }
+        if (own4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
+        }
+    }
+    const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
+#pragma unroll
+    for (int i = 0; i < LOSS_TERMS; ++i) {
+        const float v = wave_sum_dpp(s[i]);
+        if (lane == 0) red[w * LOSS_TERMS + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_TERMS) {
+        double t = 0.0;
+        for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+    }
+#ifdef VPC_ABLATE
+    STP(11);
+    if ((a.dbg & 64) && blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 3 == 0)
+        printf("step blk %d wave %d: prologue %llu E %llu g1g2 %llu out %llu R1 %llu dg2 %llu R2 %llu dg1+dz %llu R3 %llu R4 %llu R5 %llu epi %llu\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11]);
+#endif
+}
+
+static inline int row3c(int o, int L) { return o < L ? o : 16 + (o - L); }
+
+}  // namespace vpc
+
+using namespace vpc;
+
+// 1 when vpc_step_fused_bf16 is the form the library runs for this shape: obs_dim in (64, 128], obs_dim % 4 == 0 and the
+// throughput workgroup shape (tile_shape: batches whose 64-row (tile, pass) pairs do not fit two rounds of workgroups, or
+// VPC_TILE=128); the small-batch shape keeps the three 4-wave kernels
+extern "C" int vpc_step_fused_applicable(long B, int d, int L, int npass) {
+    if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L || npass < 1 || npass > 2 || B <= 0) return 0;
+    if (const char* e = getenv("VPC_STEP_FUSED")) {
+        if (atoi(e) == 0) return 0;  // A/B runs: the three-kernel form
+    }
+    return tile_shape(B, npass).small ? 0 : 1;
+}
+
+extern "C" int vpc_step_layout_bf16(int d, int L, int* img_floats, int* lds_bytes) {
+    if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (img_floats) *img_floats = StepImg::total;
+    if (lds_bytes) *lds_bytes = STEP_LDS;
+    return VPC_OK;
+}
+
+// pack_idx_c[i] >= 0: u16 index of flat parameter i inside the compact image; < 0: dword index -(idx + 1) of a value that stays
+// fp32 (the layer-1 bias).  img_template_c: zeros + the constant ones of the bias chain.
+extern "C" int vpc_step_build_indices_bf16(int d, int L, int* pack_idx_c, float* img_template_c) {
+    if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (!pack_idx_c || !img_template_c) return VPC_ERR_ARG;
+    const ParamOffsets po(d, L, d);
+    std::memset(img_template_c, 0, sizeof(float) * (size_t)StepImg::total);
+    unsigned short* u = reinterpret_cast<unsigned short*>(img_template_c);
+    const unsigned short ONE = 0x3F80;
+    for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
+        for (int i = 0; i < d; ++i) pack_idx_c[po.w1 + o * d + i] = 2 * StepImg::oW1 + c_elem<128>(r, i);
+        pack_idx_c[po.b1 + o] = -(StepImg::ob1 + r + 1);
+    }
+    img_template_c[StepImg::ob1 + pos1(H1)] = 1.f;
+    for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
+        for (int i = 0; i <= H1; ++i)
+            pack_idx_c[(i < H1) ? po.w2 + o * H1 + i : po.b2 + o] = 2 * StepImg::oW2 + c_elem<128>(r, pos1(i));
+    }
+    u[2 * StepImg::oW2 + c_elem<128>(pos2(H2), pos1(H1))] = ONE;
+    for (int o = 0; o < 2 * L; ++o) {
+        const int pr = row3c(o, L);
+        for (int i = 0; i <= H2; ++i)
+            pack_idx_c[(i < H2) ? po.w3 + o * H2 + i : po.b3 + o] = 2 * StepImg::oW3 + c_elem<64>(pr, pos2(i));
+    }
+    for (int o = 0; o < H2; ++o) {
+        const int r = pos2(o);
+        for (int i = 0; i <= L; ++i) pack_idx_c[(i < L) ? po.w4 + o * L + i : po.b4 + o] = 2 * StepImg::oW4 + c_elem<32>(r, i);
+    }
+    u[2 * StepImg::oW4 + c_elem<32>(pos2(H2), L)] = ONE;
+    for (int o = 0; o < H1; ++o) {
+        const int r = pos1(o);
+        for (int i = 0; i <= H2; ++i)
+            pack_idx_c[(i < H2) ? po.w5 + o * H2 + i : po.b5 + o] = 2 * StepImg::oW5 + c_elem<64>(r, pos2(i));
+    }
+    u[2 * StepImg::oW5 + c_elem<64>(pos1(H1), pos2(H2))] = ONE;
+    for (int o = 0; o < d; ++o)
+        for (int i = 0; i <= H1; ++i)
+            pack_idx_c[(i < H1) ? po.w6 + o * H1 + i : po.b6 + o] = 2 * StepImg::oW6 + c_elem<128>(o, pos1(i));
+    return VPC_OK;
+}
+
+namespace vpc {
+__global__ void pack_bf16c_kernel(const float* __restrict__ flat, const int* __restrict__ idx, float* __restrict__ img, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = flat[i];
+    const int e = idx[i];
+    if (e < 0) { img[-(e + 1)] = v; return; }
+    reinterpret_cast<unsigned short*>(img)[e] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+}
+}  // namespace vpc
+
+extern "C" int vpc_step_pack_weights_bf16(const float* flat_params, const int* pack_idx_c, float* img_c, int n, void* stream) {
+    if (!flat_params || !pack_idx_c || !img_c || n <= 0) return VPC_ERR_ARG;
+    hipLaunchKernelGGL(pack_bf16c_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat_params, pack_idx_c,
+                       img_c, n);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+extern "C" int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uint8_t* const* mask,
+                                   const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
+                                   const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar,
+                                   float* partE, float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L,
+                                   void* stream) {
+    if (!x || !img_c || !mask || !cA || !cE || !eps || !partE || !partD || !loss_partials) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(img_c)) return VPC_ERR_ARG;
+    if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
+    StepArgs a{};
+    a.x = x; a.img = img_c; a.eps_ml = eps_ml; a.partE = partE; a.partD = partD; a.loss_part = loss_partials;
+    a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
+    a.B = B; a.d = d; a.L = L; a.npass = npass;
+    for (int p = 0; p < npass; ++p) {
+        if (!mask[p] || !eps[p]) return VPC_ERR_ARG;
+        a.m[p] = mask[p]; a.mB[p] = maskB ? maskB[p] : nullptr; a.cA[p] = cA[p]; a.cE[p] = cE[p]; a.eps[p] = eps[p];
+        if ((uintptr_t)a.m[p] % 4 || (a.mB[p] && (uintptr_t)a.mB[p] % 4) || !aligned16(a.eps[p])) return VPC_ERR_ARG;
+    }
+    a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+#ifdef VPC_ABLATE
+    if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
+#endif
+    const int grid = a.ntiles < num_cus() ? a.ntiles : num_cus();
+    if (nblocks_out) *nblocks_out = grid;
+    auto kern = step_bf16_kernel<8>;
+    if (!lds_attr_done(reinterpret_cast<const void*>(kern), STEP_LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), STEP_LDS, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}

@@ -74,7 +74,14 @@ class FusedTrainer:
                 raise L.VpcError("the bf16 / bf16x3 kernels cover the plain encoder with obs_dim % 4 == 0 (<= 128)")
             self.pidx_bf, tmpl, self.enc_img_bf = lay.bf16_tables(self.dev)
             self.img_bf = torch.from_numpy(tmpl).to(self.dev)
-            ops.pack_weights_bf16(flat, self.pidx_bf, self.img_bf)
+            # plain bf16, obs_dim in (64, 128]: the whole-step kernel (csrc/vpc_step.hip) with its own compact image
+            self._step_ok = self.prec == 2 and 64 < lay.d <= 128
+            if self._step_ok:
+                self.pidx_c, tmpl_c = lay.step_tables(self.dev)
+                self.img_c = torch.from_numpy(tmpl_c).to(self.dev)
+            # the bf16 images follow the flat parameters lazily: an optimiser step marks them stale, the next launch that
+            # needs one re-packs it (one pack launch per step while the batch shape does not change)
+            self._stale = {"pair": True, "step": True}
         n = self.lay.n_params
         # one flat bucket: [grads (n) | loss terms (9 floats)] -> a single all-reduce per step under DP
         self.bucket = torch.zeros(n + 9, device=self.dev)
@@ -191,9 +198,18 @@ class FusedTrainer:
         co = self.coefficients(epoch, alpha, beta, beta_annealing)
         img = m._images()
         enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
-        if self.prec:  # bf16 images, re-packed from the flat parameters after every optimiser step (below)
-            enc_img, dec_img = self.img_bf[:self.enc_img_bf], self.img_bf[self.enc_img_bf:]
         two = not self.vanilla
+        use_step = bool(self.prec) and self._step_ok and ops.step_fused_applicable(B, dk, Ld, 2 if two else 1)
+        self._used_step_fused = use_step
+        if self.prec:  # bf16 images, re-packed from the flat parameters after an optimiser step (lazily, see __init__)
+            enc_img, dec_img = self.img_bf[:self.enc_img_bf], self.img_bf[self.enc_img_bf:]
+            kind = "step" if use_step else "pair"
+            if self._stale[kind]:
+                if use_step:
+                    ops.step_pack_weights_bf16(m._flat, self.pidx_c, self.img_c)
+                else:
+                    ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
+                self._stale[kind] = False
         rng0 = self.rng_offset
         # ---- random draws (mask_p and eps in ONE launch when both are drawn on the device)
         need_ml = two and co["wml"] != 0.0
@@ -230,15 +246,21 @@ class FusedTrainer:
         eml = self.eps_buf[2] if need_ml else None
         masks = [mask, mask_p] if two else [mask]
         epss = [eq, ep] if two else [eq]
-        # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
-        self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
-                    None, dk, Ld, LP, lay.mask_augm, self.prec)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
-        nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
-                          self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
-                          self.dmean, self.dlogvar, self.partD, self.loss_part, dk, Ld, LP, self.prec)
-        nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
-                          self.dlogvar, self.partE, dk, Ld, LP, lay.mask_augm, self.prec)
+        if use_step:
+            # ---- plain bf16, throughput shape: encoder forward + decoder + loss + all backward in ONE launch
+            nbE = nbD = self._timed("step_fused", ops.step_fused_bf16, x, self.img_c, masks, maskB, co["cA"], co["cE"], epss,
+                                    eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,
+                                    self.partD, self.loss_part, dk, Ld)
+        else:
+            # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
+            self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,
+                        None, dk, Ld, LP, lay.mask_augm, self.prec)
+            nbD = self._timed("decoder_fused", ops.decoder_fused, x, dec_img, masks, maskB, co["cA"], co["cE"], self.mean,
+                              self.logvar, epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
+                              self.dmean, self.dlogvar, self.partD, self.loss_part, dk, Ld, LP, self.prec)
+            nbE = self._timed("encoder_bwd", ops.encoder_bwd, x, enc_img, masks, self.h1, self.h2, self.dmean,
+                              self.dlogvar, self.partE, dk, Ld, LP, lay.mask_augm, self.prec)
         # ---- flat gradient + loss terms (+ Adam when nothing has to happen between them): one launch
         cA1 = co["cA"][1] if two else 0.0
         self.last_blocks = (nbE, nbD)
@@ -250,7 +272,7 @@ class FusedTrainer:
                         self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                         self.step_count, self.pidx, img, self.inv)
             if self.prec:
-                ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
+                self._stale = {"pair": True, "step": True}
             return
         ops.reduce_step(self.partE, nbE, lay.enc_part, self.partD, nbD, lay.dec_part,
                     self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"],
@@ -267,7 +289,7 @@ class FusedTrainer:
                         None if _state is None else _state[0:1],
                         loss_in=self.out9 if self.dp else None, accum=self.accum if self.dp else None)
             if self.prec:
-                ops.pack_weights_bf16(m._flat, self.pidx_bf, self.img_bf)
+                self._stale = {"pair": True, "step": True}
         elif self.dp:
             self.accum += self.out9[0]
 

@@ -121,6 +121,26 @@ def decoder_fused(x, dec_img, maskA, maskB, cA, cE, mean, logvar, eps, eps_ml, b
     return nb.value
 
 
+def step_fused_applicable(B, d, Ld, npass):
+    return bool(lib().vpc_step_fused_applicable(int(B), d, Ld, npass))
+
+
+def step_pack_weights_bf16(flat, pack_idx_c, img_c):
+    check(lib().vpc_step_pack_weights_bf16(ptr(flat), ptr(pack_idx_c), ptr(img_c), flat.numel(), stream_ptr()),
+          "vpc_step_pack_weights_bf16")
+
+
+def step_fused_bf16(x, img_c, masks, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE, partD, loss_part,
+                    d, Ld):
+    """Whole step (encoder fwd + decoder + loss + all backward) in one launch; returns the number of partial blocks."""
+    n = len(masks)
+    nb = C.c_int(0)
+    check(lib().vpc_step_fused_bf16(ptr(x), ptr(img_c), n, ptr_array(masks), ptr_array(maskB), farray(cA), farray(cE),
+                                    ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml, inv_B, x_logvar, ptr(partE), ptr(partD),
+                                    ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_step_fused_bf16")
+    return nb.value
+
+
 def loss_finalize(loss_part, nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d, out9, accum=None):
     check(lib().vpc_loss_finalize(ptr(loss_part), nblocks, cA0, cE0, cA1, bq, bp, cr, wml, B_local, B_global, d,
                                   ptr(out9), ptr(accum), stream_ptr()), "vpc_loss_finalize")
