@@ -338,17 +338,21 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
  * vpc_step_pack_weights_bf16 writes img_c from the flat parameters (after every optimiser step).
  * vpc_step_fused_bf16: arguments as vpc_decoder_fused (mask[p] is the encoder mask AND the first loss mask of pass p;
  * eps[p] [B][16] padded rows, eps_ml likewise); partE / partD / loss_partials are written in the layouts of
- * vpc_encoder_bwd / vpc_decoder_fused (*nblocks_out blocks each), so vpc_reduce_step(_adam) consumes them unchanged. */
+ * vpc_encoder_bwd / vpc_decoder_fused (*nblocks_out blocks each), so vpc_reduce_step(_adam) consumes them unchanged.
+ * The kernel runs two sweeps over a workgroup's tiles (decoder-side gradients, then encoder-side gradients: csrc/vpc_step.hip);
+ * the seeds on (mean | logvar) cross from one to the other through `workspace` as packed bf16, 16 bytes per lane. */
 /* 1 when the library runs a (B, d, L, npass) bf16 step through vpc_step_fused_bf16 (throughput workgroup shape), else 0 */
 int vpc_step_fused_applicable(long B, int d, int L, int npass);
+/* floats of the caller-owned `workspace` of vpc_step_fused_bf16 for B rows (16-byte aligned; contents are scratch) */
+long vpc_step_workspace_floats(long B);
 int vpc_step_layout_bf16(int d, int L, int* img_floats, int* lds_bytes);
 int vpc_step_build_indices_bf16(int d, int L, int* pack_idx_c, float* img_template_c);
 int vpc_step_pack_weights_bf16(const float* flat_params, const int* pack_idx_c, float* img_c, int n, void* stream);
 int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uint8_t* const* mask,
                         const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
                         const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar,
-                        float* partE, float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L,
-                        void* stream);
+                        float* partE, float* partD, double* loss_partials, float* workspace, int* nblocks_out, long B,
+                        int d, int L, void* stream);
 
 #ifdef __cplusplus
 }

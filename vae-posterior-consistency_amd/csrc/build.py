@@ -38,10 +38,26 @@ def _compile(src, asm=False):
 
 
 def build_ablate():
-    """Diagnostic library with the VPC_DEBUG ablation switches compiled in (never loaded by the product)."""
+    """Diagnostic library with the VPC_DEBUG ablation switches / phase stamps compiled in (never loaded by the product;
+    VPC_LIB points a process at it).  Objects go to build_ablate/, compiled in parallel."""
     out = os.path.join(HERE, "libvpc_hip_ablate.so")
-    cmd = [HIPCC] + FLAGS + ["-DVPC_ABLATE", "-shared", "-o", out] + [os.path.join(HERE, s) for s in SRCS]
-    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    bdir = os.path.join(HERE, "build_ablate")
+    os.makedirs(bdir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HDRS]
+        if _newer(obj, deps):
+            r = subprocess.run([HIPCC] + FLAGS + ["-DVPC_ABLATE", "-c", os.path.join(HERE, src), "-o", obj], cwd=HERE,
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, SRCS))
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + objs + ["-ldl"], cwd=HERE,
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
     return out

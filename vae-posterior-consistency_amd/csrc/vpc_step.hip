@@ -151,6 +151,7 @@ struct StepArgs {
     float* partE;
     float* partD;
     double* loss_part;
+    float* ws;              // packed (dmean | dlogvar) seeds between the sweeps: [tiles][2][512 threads] x 16 bytes
     float bq, bp, cr, wml, inv_B, x_logvar;
     long B;
     int d, L, npass, ntiles;
@@ -163,6 +164,14 @@ struct StepArgs {
 #define STP(i) do {} while (0)
 #endif
 
+// Two sweeps over the workgroup's tiles, so that only HALF of the gradient accumulators is live at any time (all 100 of them
+// beside the working set of the decoder phase do not fit 256 registers: hipcc then parks the accumulators in scratch and
+// reloads them around every staging round - measured 206 us against 148 us for a variant that merely spilled less):
+//   sweep 1 (decoder accumulators dW6, dW5, dW4 + dW3: 52 registers): per tile  E(q), E(p) - one x read, statistics and the
+//           packed h2 of both passes kept (32 registers) - then per pass  D: reparameterise, decoder, loss, R1, R2, dz, KL seeds,
+//           R3 (dW4, dW3); the packed seeds (dmean | dlogvar: 16 bytes per lane) go to a small workspace (8 MB at B = 65 536)
+//   sweep 2 (encoder accumulators dW1, dW2, db1: 48 registers): per tile and pass  E again (h1, h2: the recompute costs ~60
+//           bf16 MFMAs per wave), seeds back from the workspace, dh2, R4, dh1, R5.
 template <int DT>
 __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -182,12 +191,8 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const int lrow = w * 16 + c;
     const bool two = a.npass == 2;
+    constexpr int KB1 = (DT + 1) / 2;
 
-    // ---- x / mask rows of one tile in C layout (range-checked: rows past B read 0; columns past d read column 0 and are
-    // cleared through the mask word)
-    const int cq = (4 * q + 3 < a.d) ? 4 * q : 0;
-    const int vo = lrow * a.d + cq;
-    auto col_off = [&](int t) { return (t < DT / 2 || 16 * t + 4 * q + 3 < a.d) ? 16 * t : 0; };
     auto mask_rsrc = [&](const uint8_t* mp, long row0) {
         const long rem = (a.B - row0) * (long)a.d;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mp) + row0 * a.d, 0,
@@ -196,436 +201,572 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     load_image<13>(lds, a.img, StepImg::total);
     __syncthreads();
     STP(0);
-
-    f32x4 acc6[H1T], acc5[H2T], acc4 = zero4(), acc1[H1T], acc2[H2T], acc3 = zero4(), accb = zero4();
-#pragma unroll
-    for (int t = 0; t < H1T; ++t) { acc6[t] = zero4(); acc1[t] = zero4(); }
-#pragma unroll
-    for (int t = 0; t < H2T; ++t) { acc5[t] = zero4(); acc2[t] = zero4(); }
-    float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
-    const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
-    constexpr float HL2PI = 0.91893853320467274f;
     const bool own6 = w < DT, own2 = w < H1T, own4 = w < H2T;
-    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    const Op ones = __builtin_bit_cast(Op, ones_u);
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long row0 = (long)tile * TILE_ROWS;
-        const bool ok = row0 + lrow < a.B;
+    // x rows of a tile in C layout (range-checked: rows past B read 0; columns past d read column 0 and are cleared through the
+    // mask word), and the packed layer-1 operand x * mask of one pass
+    auto load_x = [&](long row0, f32x4 (&xr)[DT], int cc, int qq) {
         const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
-        auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
-            return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
-        };
-        f32x4 muQ = zero4(), lvQ = zero4(), muP = zero4(), lvP = zero4();
-        // stage s: 0 = statistics of pass 1 only (two-pass models), 1 = pass 0, 2 = pass 1
-        for (int s = two ? 0 : 1; s <= a.npass; ++s) {
-            const int p = s == 0 ? 1 : s - 1;
-            asm volatile("" ::: "memory");  // the weight image never changes: keep LDS weight reads inside the stage
+        const int vo = (w * 16 + cc) * a.d + ((4 * qq + 3 < a.d) ? 4 * qq : 0);
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            xr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rx, 4 * (vo + ((t < DT / 2 || 16 * t + 4 * qq + 3 < a.d) ? 16 * t : 0)), 0, 0));
+    };
+    auto load_m = [&](const uint8_t* mp, long row0, uint32_t (&mw)[DT], int cc, int qq) {
+        const __amdgpu_buffer_rsrc_t rm = mask_rsrc(mp, row0);
+        const int vo = (w * 16 + cc) * a.d + ((4 * qq + 3 < a.d) ? 4 * qq : 0);
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            mw[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rm, vo + ((t < DT / 2 || 16 * t + 4 * qq + 3 < a.d) ? 16 * t : 0), 0, 0);
+    };
+    // mask words of columns past d (possible in the last DT / 2 tiles only) -> 0: such a column is never observed
+    auto clear_cols = [&](uint32_t (&mw)[DT], int qq) {
+#pragma unroll
+        for (int t = DT / 2; t < DT; ++t) mw[t] &= opaque_mask(16 * t + 4 * qq + 3 < a.d);
+    };
+    auto make_xb = [&](const f32x4 (&xr)[DT], const uint32_t (&mw)[DT], Op (&xb)[KB1], int qq) {
+        f32x4 xprev = zero4();
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const f32x4 xi = xr[t] * mask_to_f32(mw[t]);  // x.float() * mask  (VAE.py:388)
+            if (t & 1) xb[t >> 1] = pack2(xprev, xi);
+            else if (t + 1 == DT) xb[t >> 1] = pack2(xi, zero4());
+            xprev = xi;
+        }
+    };
+    // encoder forward of one pass from its packed input: h1 / h2 as packed operands, (mean | logvar) tiles
+    auto enc_fwd = [&](const Op (&xb)[KB1], Op (&h1b)[4], Op (&h2b)[2], f32x4& mu, f32x4& lv, int cc, int qq, bool ok) {
+        f32x4 hprev = zero4();
+        c_layer_fwd<128, KB1, H1T>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
+            const f32x4 h = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq));
+            if (mt & 1) h1b[mt >> 1] = pack2(hprev, h);
+            else if (mt + 1 == H1T) h1b[mt >> 1] = pack2(h, zero4());
+            hprev = h;
+        });
+        c_layer_fwd<128, 4, H2T>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
+            const f32x4 h = relu4(acc);
+            if (mt & 1) h2b[mt >> 1] = pack2(hprev, h);
+            hprev = h;
+        });
+        f32x4 ml[2];
+        c_layer_fwd<64, 2, 2>(W3, h2b, cc, qq, [&](int mt, f32x4 acc) { ml[mt] = acc; });
+        const uint32_t okm = opaque_mask(ok);  // rows past B: statistics 0 (as the range-checked workspace loads gave)
+        mu = and4(ml[0], okm);
+        lv = and4(ml[1], okm);
+    };
+    // workspace of the packed seeds: [tile][pass][thread] 16 bytes
+    auto ws_ptr = [&](int tile, int p) { return reinterpret_cast<u32x4*>(a.ws) + ((long)tile * 2 + p) * THREADS + threadIdx.x; };
+
+    // ============================================================================================================ sweep 1
+    {
+        f32x4 acc6[H1T], acc5[H2T], acc4 = zero4(), acc3 = zero4();
+#pragma unroll
+        for (int t = 0; t < H1T; ++t) acc6[t] = zero4();
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) acc5[t] = zero4();
+        float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
+        const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
+        constexpr float HL2PI = 0.91893853320467274f;
+
+        for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+            const long row0 = (long)tile * TILE_ROWS;
+            const bool ok = row0 + lrow < a.B;
+            const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
+            auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
+                return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
+            };
+            asm volatile("" ::: "memory");  // the weight image never changes: keep LDS weight reads inside the tile
             int cc = c, qq = q;
             launder(cc, qq);
-            const __amdgpu_buffer_rsrc_t rmA = mask_rsrc(a.m[p], row0);
-            // ================================================================ E: encoder forward
-            Op h1b[4], h2b[2];
-            f32x4 mu, lv;
-            {
-                f32x4 xin[DT];
+            // ---------------- the tile's inputs: read ONCE and kept in registers for both passes of this sweep - x (32 registers),
+            // the mask words of both passes (16) and eps (8).  (Re-reading them per phase from L2 does not work: 32 workgroups
+            // per XCD stream 100 KB each through a 4 MB L2 beside partial blocks and scratch - measured 390 MB fetched per
+            // launch with per-phase re-reads.)
+            // Everything that differs between the passes is held as a (current, other) pair and SWAPPED at the end of a pass:
+            // selecting per pass (p == 0 ? q : p) makes a second live copy of whatever is selected.
+            f32x4 xr[DT];
+            uint32_t mw0[DT], mw1[DT];
+            load_x(row0, xr, cc, qq);
+            load_m(a.m[0], row0, mw0, cc, qq);
+            if (two) load_m(a.m[1], row0, mw1, cc, qq);
+            else {
 #pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const f32x4 xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(t)), 0, 0));
-                    const uint32_t mw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(t), 0, 0);
-                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
-                    xin[t] = xr * mask_to_f32(mw & vm);  // x.float() * mask  (VAE.py:388)
-                }
-                Op xb[(DT + 1) / 2];
-#pragma unroll
-                for (int kb = 0; kb < (DT + 1) / 2; ++kb) xb[kb] = pack2(xin[2 * kb], 2 * kb + 1 < DT ? xin[2 * kb + 1] : zero4());
-                f32x4 hprev = zero4();
-                c_layer_fwd<128, (DT + 1) / 2, H1T>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
-                    const f32x4 h = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
-                    if (mt & 1) h1b[mt >> 1] = pack2(hprev, h);
-                    else if (mt + 1 == H1T) h1b[mt >> 1] = pack2(h, zero4());
-                    hprev = h;
-                });
-                launder(cc, qq);
-                c_layer_fwd<128, 4, H2T>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
-                    const f32x4 h = relu4(acc);
-                    if (mt & 1) h2b[mt >> 1] = pack2(hprev, h);
-                    hprev = h;
-                });
-                f32x4 ml[2];
-                c_layer_fwd<64, 2, 2>(W3, h2b, cc, qq, [&](int mt, f32x4 acc) { ml[mt] = acc; });
-                const uint32_t okm = opaque_mask(ok);  // rows past B: statistics 0 (as the range-checked workspace loads gave)
-                mu = and4(ml[0], okm);
-                lv = and4(ml[1], okm);
+                for (int t = 0; t < DT; ++t) mw1[t] = 0u;
             }
-            if (p == 0) { muQ = mu; lvQ = lv; } else { muP = mu; lvP = lv; }
-            STP(1);
-            if (s == 0) continue;
-            const f32x4 mo = p == 0 ? muP : muQ, lo = p == 0 ? lvP : lvQ;  // the other pass's statistics
-            // ================================================================ D: reparameterise, decoder, loss, decoder backward
-            const f32x4 e = ld_lat(a.eps[p]);
-            f32x4 z;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = mu[j] + ((4 * q + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
-            const bool skip_dec = a.cA[p] == 0.f && a.cE[p] == 0.f;
-            f32x4 dz = zero4();
-            Op zb;
-            Op dmlb;  // packed (dmean | dlogvar) of this pass
-            VPC_CUT();
-            if (!skip_dec) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * q + j == a.L) z[j] = 1.f;  // constant feature that drives the bias chain
-                zb = pack2(z, zero4());
-                Op g1b[2], g2b[4];
-                uint32_t gm1 = 0, gm2 = 0;
-                {
-                    f32x4 hprev = zero4();
-                    const Op zin[1] = {zb};
-                    c_layer_fwd<32, 1, H2T>(W4, zin, cc, qq, [&](int mt, f32x4 acc) {
-                        const f32x4 h = relu4(acc);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) gm1 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
-                        if (mt & 1) g1b[mt >> 1] = pack2(hprev, h);
-                        hprev = h;
-                    });
+            f32x4 e = ld_lat(a.eps[0]);
+            clear_cols(mw0, qq);
+            if (two) clear_cols(mw1, qq);
+            // ---------------- E: statistics and packed h2 of both passes
+            f32x4 muQ, lvQ, muP = zero4(), lvP = zero4();
+            Op h2q[2], h2p[2];
+            {
+                Op xb[KB1], h1b[4];
+                make_xb(xr, mw0, xb, qq);
+                enc_fwd(xb, h1b, h2q, muQ, lvQ, cc, qq, ok);
+                if (two) {
                     launder(cc, qq);
-                    c_layer_fwd<64, 2, H1T>(W5, g1b, cc, qq, [&](int mt, f32x4 acc) {
-                        const f32x4 h = relu4(acc);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) gm2 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
-                        if (mt & 1) g2b[mt >> 1] = pack2(hprev, h);
-                        else if (mt + 1 == H1T) g2b[mt >> 1] = pack2(h, zero4());
-                        hprev = h;
-                    });
+                    make_xb(xr, mw1, xb, qq);
+                    enc_fwd(xb, h1b, h2p, muP, lvP, cc, qq, ok);
                 }
+            }
+            STP(1);
+            for (int p = 0; p < a.npass; ++p) {
+                asm volatile("" ::: "memory");
                 launder(cc, qq);
-                STP(2);
+                // (current, other) = (q, p) in pass 0 and (p, q) in pass 1: see the swaps at the end of the pass
+                f32x4 &mu = muQ, &lv = lvQ, &mo = muP, &lo = lvP;
+                f32x4 z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[j] = mu[j] + ((4 * q + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
+                // (a pass whose reconstruction terms carry no weight - cA = cE = 0: the p pass of ml_reg - still runs the decoder:
+                // its seeds are exact zeros, so it adds nothing; a branch around the whole decoder phase cost 130 bytes of
+                // scratch per lane in every configuration)
+                f32x4 dz = zero4();
                 VPC_CUT();
-                // ---------------- output tiles: forward, loss terms, d / d pre-activation
-                Op dpreb[(DT + 1) / 2];
                 {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    constexpr float NLOG2E = -1.4426950408889634f;
-                    f32x2 sa2 = {0.f, 0.f}, se2 = {0.f, 0.f};
-                    const bool hasB = a.mB[p] != nullptr;
-                    const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
-                    const __amdgpu_buffer_rsrc_t rmB = mask_rsrc(hasB ? a.mB[p] : a.m[p], row0);
-                    auto fetch = [&](int mt, f32x4& xv, uint32_t& ua, uint32_t& ub) {
-                        xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(mt)), 0, 0));
-                        ua = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(mt), 0, 0);
-                        ub = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmB, vo + col_off(mt), 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j == a.L) z[j] = 1.f;  // constant feature that drives the bias chain
+                    const Op zb = pack2(z, zero4());
+                    Op g2b[4];
+                    uint32_t gm2 = 0;
+                    const Op zin[1] = {zb};
+                    // g1 = relu(W4~ z): formed here for the forward and AGAIN in front of R2 (4 MFMAs instead of 8 registers held
+                    // across the output-tile phase)
+                    auto make_g1 = [&](Op (&g1b)[2], uint32_t& gm1) {
+                        f32x4 hprev = zero4();
+                        gm1 = 0;
+                        c_layer_fwd<32, 1, H2T>(W4, zin, cc, qq, [&](int mt, f32x4 acc) {
+                            const f32x4 h = relu4(acc);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) gm1 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
+                            if (mt & 1) g1b[mt >> 1] = pack2(hprev, h);
+                            hprev = h;
+                        });
                     };
-                    f32x4 xv_n, dprev = zero4();
-                    uint32_t ua_n, ub_n;
-                    fetch(0, xv_n, ua_n, ub_n);
-                    Op w6n[4];
+                    {
+                        Op g1b[2];
+                        uint32_t gm1_unused;
+                        make_g1(g1b, gm1_unused);
+                        launder(cc, qq);
+                        f32x4 hprev = zero4();
+                        c_layer_fwd<64, 2, H1T>(W5, g1b, cc, qq, [&](int mt, f32x4 acc) {
+                            const f32x4 h = relu4(acc);
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) w6n[kb] = c_wfrag<128>(W6, 0, kb, cc, qq);
-#pragma unroll
-                    for (int mt = 0; mt < DT; ++mt) {
-                        VPC_CUT();
-                        const f32x4 xv = xv_n;
-                        uint32_t ua = ua_n, ub = ub_n;
-                        if (mt + 1 < DT) fetch(mt + 1, xv_n, ua_n, ub_n);
-                        Op w6c[4];
-#pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) w6c[kb] = w6n[kb];
-                        if (mt + 1 < DT) {
-#pragma unroll
-                            for (int kb = 0; kb < 4; ++kb) w6n[kb] = c_wfrag<128>(W6, mt + 1, kb, cc, qq);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        f32x4 pre = zero4();
-#pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) pre = VPC_MFMA_BF(w6c[kb], g2b[kb], pre);
-                        if (mt >= DT / 2) {
-                            const uint32_t vm = opaque_mask(16 * mt + 4 * q + 3 < a.d);
-                            ua &= vm;
-                            ub &= vm;
-                        }
-                        const f32x4 mA = mask_to_f32(ua);
-                        const f32x4 mE = mA * (1.f - mask_to_f32(ub));  // no second mask: ub aliases ua, mA (1 - mA) = 0
-                        f32x4 dp4;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const f32x2 p2 = {pre[2 * h], pre[2 * h + 1]}, x2 = {xv[2 * h], xv[2 * h + 1]};
-                            const f32x2 a2 = {mA[2 * h], mA[2 * h + 1]}, e2 = {mE[2 * h], mE[2 * h + 1]};
-                            const f32x2 en = p2 * NLOG2E;
-                            const f32x2 den = f32x2{__builtin_amdgcn_exp2f(en[0]), __builtin_amdgcn_exp2f(en[1])} + 1.f;
-                            const f32x2 xh = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-                            const f32x2 diff = xh - x2;
-                            const f32x2 t = __builtin_elementwise_fma(diff * diff, f32x2{hinv_s2, hinv_s2}, f32x2{half_lv, half_lv});
-                            sa2 = __builtin_elementwise_fma(a2, t, sa2);
-                            se2 = __builtin_elementwise_fma(e2, t, se2);
-                            const f32x2 wgt = __builtin_elementwise_fma(f32x2{kE, kE}, e2, a2 * kA);
-                            const f32x2 dp = (wgt * diff) * __builtin_elementwise_fma(-xh, xh, xh);
-                            dp4[2 * h] = dp[0];
-                            dp4[2 * h + 1] = dp[1];
-                        }
-                        asm volatile("" : "+v"(dp4[0]), "+v"(dp4[1]), "+v"(dp4[2]), "+v"(dp4[3]), "+v"(sa2), "+v"(se2));
-                        if (mt & 1) dpreb[mt >> 1] = pack2(dprev, dp4);
-                        else if (mt + 1 == DT) dpreb[mt >> 1] = pack2(dp4, zero4());
-                        dprev = dp4;
+                            for (int j = 0; j < 4; ++j) gm2 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
+                            if (mt & 1) g2b[mt >> 1] = pack2(hprev, h);
+                            else if (mt + 1 == H1T) g2b[mt >> 1] = pack2(h, zero4());
+                            hprev = h;
+                        });
                     }
-                    const float sa = sa2[0] + sa2[1], se = se2[0] + se2[1];
-                    if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
-                }
-                STP(3);
-                VPC_CUT();
-                launder(cc, qq);
-                // ---------------- R1: dW6~ += dpre^T g2   (owner: wave w -> out tile w, all 7 in tiles)
-                __syncthreads();
+                    launder(cc, qq);
+                    STP(2);
+                    VPC_CUT();
+                    // ---------------- output tiles: forward, loss terms, d / d pre-activation.  dpre goes straight into its R1
+                    // staging slots (tile mt -> slot mt, 8 bytes per lane and tile) instead of growing to 16 registers across
+                    // the loop; the dgrad below reads the lane's own chunks back.  The barrier: every wave is past the reads of
+                    // the previous staging round.
+                    __syncthreads();
+                    {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        constexpr float NLOG2E = -1.4426950408889634f;
+                        f32x2 sa2 = {0.f, 0.f}, se2 = {0.f, 0.f};
+                        const bool hasB = a.mB[p] != nullptr;  // (the host checked: the second mask IS the other pass's mask)
+                        const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
+                        Op w6f[4];
 #pragma unroll
-                for (int kb = 0; kb < (DT + 1) / 2; ++kb) st_op<DT>(st, lrow, 0, kb, qq, dpreb[kb]);
+                        for (int kb = 0; kb < 4; ++kb) w6f[kb] = c_wfrag<128>(W6, 0, kb, cc, qq);
+                        const int so = bf_stage_off<ST_FT>(16 * w + cc, 0, qq);  // slot mt: + 64 mt dwords
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, g2b[kb]);
-                __syncthreads();
-                if (own6) {
+                        for (int mt = 0; mt < DT; ++mt) {
+                            VPC_CUT();
+                            const f32x4 xv = xr[mt];
+                            const uint32_t ua = mw0[mt];
+                            const uint32_t ub = hasB ? mw1[mt] : ua;
+                            f32x4 pre = zero4();
 #pragma unroll
-                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const Op fa = st_frag(st, w, kb, 16 * qq + cc);
-                        Op fb = st_frag(st, 8, kb, 16 * qq + cc);
+                            for (int kb = 0; kb < 4; ++kb) pre = VPC_MFMA_BF(w6f[kb], g2b[kb], pre);
+                            // the next tile's fragments are requested behind this tile's MFMAs and arrive under its loss math
+                            if (mt + 1 < DT) {
 #pragma unroll
-                        for (int nt = 0; nt < H1T; ++nt) {
-                            const Op fn = st_frag(st, 8 + (nt + 1 < H1T ? nt + 1 : nt), kb, 16 * qq + cc);
+                                for (int kb = 0; kb < 4; ++kb) w6f[kb] = c_wfrag<128>(W6, mt + 1, kb, cc, qq);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
-                            acc6[nt] = VPC_MFMA_BF(fa, fb, acc6[nt]);
-                            fb = fn;
+                            const f32x4 mA = mask_to_f32(ua);
+                            const f32x4 mE = mA * (1.f - mask_to_f32(ub));  // no second mask: ub aliases ua, mA (1 - mA) = 0
+                            f32x4 dp4;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x2 p2 = {pre[2 * h], pre[2 * h + 1]}, x2 = {xv[2 * h], xv[2 * h + 1]};
+                                const f32x2 a2 = {mA[2 * h], mA[2 * h + 1]}, e2 = {mE[2 * h], mE[2 * h + 1]};
+                                const f32x2 en = p2 * NLOG2E;
+                                const f32x2 den = f32x2{__builtin_amdgcn_exp2f(en[0]), __builtin_amdgcn_exp2f(en[1])} + 1.f;
+                                const f32x2 xh = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                                const f32x2 diff = xh - x2;
+                                const f32x2 t = __builtin_elementwise_fma(diff * diff, f32x2{hinv_s2, hinv_s2}, f32x2{half_lv, half_lv});
+                                sa2 = __builtin_elementwise_fma(a2, t, sa2);
+                                se2 = __builtin_elementwise_fma(e2, t, se2);
+                                const f32x2 wgt = __builtin_elementwise_fma(f32x2{kE, kE}, e2, a2 * kA);
+                                const f32x2 dp = (wgt * diff) * __builtin_elementwise_fma(-xh, xh, xh);
+                                dp4[2 * h] = dp[0];
+                                dp4[2 * h + 1] = dp[1];
+                            }
+                            asm volatile("" : "+v"(dp4[0]), "+v"(dp4[1]), "+v"(dp4[2]), "+v"(dp4[3]), "+v"(sa2), "+v"(se2));
+                            *reinterpret_cast<u32x2*>(st + so + 64 * mt) = u32x2{pk_bf16(dp4[0], dp4[1]), pk_bf16(dp4[2], dp4[3])};
+                        }
+                        const float sa = sa2[0] + sa2[1], se = se2[0] + se2[1];
+                        if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
+                    }
+                    STP(3);
+                    VPC_CUT();
+                    launder(cc, qq);
+                    // ---------------- R1: dW6~ += dpre^T g2   (owner: wave w -> out tile w, all 7 in tiles)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, g2b[kb]);
+                    __syncthreads();
+                    // (all fragment reads of a k-block are in flight before its first MFMA: issued one by one in front of their
+                    // MFMA every product waits a full LDS round trip - the rounds were 4-6 k cycles of that)
+                    if (own6) {
+#pragma unroll
+                        for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const Op fa = st_frag(st, w, kb, 16 * qq + cc);
+                            Op fb[H1T];
+#pragma unroll
+                            for (int nt = 0; nt < H1T; ++nt) fb[nt] = st_frag(st, 8 + nt, kb, 16 * qq + cc);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int nt = 0; nt < H1T; ++nt) acc6[nt] = VPC_MFMA_BF(fa, fb[nt], acc6[nt]);
                         }
                     }
+                    STP(4);
+                    VPC_CUT();
+                    launder(cc, qq);
+                    // ---------------- dg2 = relu'(g2) * (W6~^T dpre): B operands = the lane's own dpre chunks, back from their
+                    // staging slots (own writes: no barrier)
+                    Op dpreb[KB1];
+                    {
+                        const int so = bf_stage_off<ST_FT>(16 * w + cc, 0, qq);
+#pragma unroll
+                        for (int kb = 0; kb < KB1; ++kb) {
+                            const u32x2 lo2 = *reinterpret_cast<const u32x2*>(st + so + 128 * kb);
+                            const u32x2 hi2 = (2 * kb + 1 < DT) ? *reinterpret_cast<const u32x2*>(st + so + 128 * kb + 64) : u32x2{0u, 0u};
+                            dpreb[kb] = __builtin_bit_cast(Op, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+                        }
+                    }
+                    Op dg2b[4];
+                    {
+                        f32x4 hprev = zero4();
+                        c_layer_T<128, KB1, H1T, DT>(W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                            const f32x4 h = gate_bits(acc, gm2, mt);
+                            if (mt & 1) dg2b[mt >> 1] = pack2(hprev, h);
+                            else if (mt + 1 == H1T) dg2b[mt >> 1] = pack2(h, zero4());
+                            hprev = h;
+                        });
+                    }
+                    STP(5);
+                    VPC_CUT();
+                    launder(cc, qq);
+                    // ---------------- R2: dW5~ += dg2^T g1   (owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3)
+                    Op g1b[2];
+                    uint32_t gm1;
+                    make_g1(g1b, gm1);
+                    __syncthreads();
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dg2b[kb]);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 8, kb, qq, g1b[kb]);
+                    __syncthreads();
+                    {
+                        const int nt5 = w & 3, mt5 = 4 * (w >> 2);
+#pragma unroll
+                        for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const Op fb = st_frag(st, 8 + nt5, kb, 16 * qq + cc);
+                            Op fa[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fa[i] = st_frag(st, (i < 3 || w < 4) ? mt5 + i : mt5, kb, 16 * qq + cc);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < 3 || w < 4) acc5[i] = VPC_MFMA_BF(fa[i], fb, acc5[i]);
+                        }
+                    }
+                    STP(6);
+                    VPC_CUT();
+                    launder(cc, qq);
+                    // ---------------- dg1 = relu'(g1) * (W5~^T dg2);  dz = W4~^T dg1
+                    Op dg1b[2];
+                    {
+                        f32x4 hprev = zero4();
+                        c_layer_T<64, 4, H2T, H1T>(W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                            const f32x4 h = gate_bits(acc, gm1, mt);
+                            if (mt & 1) dg1b[mt >> 1] = pack2(hprev, h);
+                            hprev = h;
+                        });
+                        c_layer_T<32, 2, 1, H2T>(W4, dg1b, 16 * qq + cc, [&](int, f32x4 acc) { dz = acc; });
+                    }
+                    // R3's decoder operands (the seeds and h2 follow below)
+                    __syncthreads();
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dg1b[kb]);
+                    st_op<1>(st, lrow, 8, 0, qq, zb);
                 }
-                STP(4);
-                VPC_CUT();
-                launder(cc, qq);
-                // ---------------- dg2 = relu'(g2) * (W6~^T dpre)
-                Op dg2b[4];
+                STP(7);
+                // ---------------- KL terms, their seeds, total seeds on (mean | logvar)
+                Op dmlb;
                 {
-                    f32x4 hprev = zero4();
-                    c_layer_T<128, (DT + 1) / 2, H1T, DT>(W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                        const f32x4 h = gate_bits(acc, gm2, mt);
-                        if (mt & 1) dg2b[mt >> 1] = pack2(hprev, h);
-                        else if (mt + 1 == H1T) dg2b[mt >> 1] = pack2(h, zero4());
-                        hprev = h;
-                    });
-                }
-                STP(5);
-                VPC_CUT();
-                launder(cc, qq);
-                // ---------------- R2: dW5~ += dg2^T g1   (owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3)
-                __syncthreads();
+                    f32x4 dmu, dlv;
+                    const float b0 = (p == 0) ? a.bq : a.bp;
+                    const float sgn = (p == 0) ? 1.f : -1.f;
+                    const float crr = two ? a.cr : 0.f;
+                    float kl0 = 0.f, klr = 0.f;
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dg2b[kb]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float elv = __expf(lv[j]);
+                        kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
+                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                        const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
+                        klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+                        const float dm = b0 * mu[j] + sgn * crr * diff * eip;
+                        const float dl = b0 * 0.5f * (elv - 1.f) + crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
+                        dmu[j] = dm * a.inv_B;
+                        dlv[j] = dl * a.inv_B;
+                    }
+                    if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
+                    if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+                        const f32x4 e3 = ld_lat(a.eps_ml);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 8, kb, qq, g1b[kb]);
-                __syncthreads();
-                {
-                    const int nt5 = w & 3, mt5 = 4 * (w >> 2);
-#pragma unroll
-                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const Op fb = st_frag(st, 8 + nt5, kb, 16 * qq + cc);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (i < 3 || w < 4) {
-                                const Op fa = st_frag(st, mt5 + i, kb, 16 * qq + cc);
-                                acc5[i] = VPC_MFMA_BF(fa, fb, acc5[i]);
+                        for (int j = 0; j < 4; ++j) {
+                            const bool live = ok && 4 * q + j < a.L;
+                            const float e3j = (4 * q + j < a.L) ? e3[j] : 0.f;
+                            const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                            const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                            const float sq = __expf(0.5f * lq), eip = __expf(-lp);
+                            const float dlt = mq + e3j * sq - mp;
+                            const float g = a.wml * dlt * eip * a.inv_B;
+                            if (p == 0) {
+                                if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                                dmu[j] += g;
+                                dlv[j] += g * e3j * 0.5f * sq;
+                            } else {
+                                dmu[j] -= g;
+                                dlv[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
                             }
                         }
                     }
-                }
-                STP(6);
-                VPC_CUT();
-                launder(cc, qq);
-                // ---------------- dg1 = relu'(g1) * (W5~^T dg2);  dz = W4~^T dg1
-                Op dg1b[2];
-                {
-                    f32x4 hprev = zero4();
-                    c_layer_T<64, 4, H2T, H1T>(W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                        const f32x4 h = gate_bits(acc, gm1, mt);
-                        if (mt & 1) dg1b[mt >> 1] = pack2(hprev, h);
-                        hprev = h;
-                    });
-                    c_layer_T<32, 2, 1, H2T>(W4, dg1b, 16 * qq + cc, [&](int, f32x4 acc) { dz = acc; });
-                }
-                // R3's A operands of this pass (B operands and dml follow below, after the seeds)
-                __syncthreads();
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dg1b[kb]);
-                st_op<1>(st, lrow, 8, 0, qq, zb);
-            } else {
-                __syncthreads();
-            }
-            STP(7);
-            // ================================================================ KL terms, their seeds, total seeds on (mean | logvar)
-            {
-                f32x4 dmu, dlv;
-                const float b0 = (p == 0) ? a.bq : a.bp;
-                const float sgn = (p == 0) ? 1.f : -1.f;
-                const float crr = two ? a.cr : 0.f;
-                float kl0 = 0.f, klr = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float elv = __expf(lv[j]);
-                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
-                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
-                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
-                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
-                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
-                    const float dl = b0 * 0.5f * (elv - 1.f) + crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
-                    dmu[j] = dm * a.inv_B;
-                    dlv[j] = dl * a.inv_B;
-                }
-                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
-                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
-                    const f32x4 e3 = ld_lat(a.eps_ml);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool live = ok && 4 * q + j < a.L;
-                        const float e3j = (4 * q + j < a.L) ? e3[j] : 0.f;
-                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
-                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
-                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
-                        const float dlt = mq + e3j * sq - mp;
-                        const float g = a.wml * dlt * eip * a.inv_B;
-                        if (p == 0) {
-                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
-                            dmu[j] += g;
-                            dlv[j] += g * e3j * 0.5f * sq;
-                        } else {
-                            dmu[j] -= g;
-                            dlv[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
-                        }
-                    }
-                }
-                if (!skip_dec) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float ef = (4 * q + j < a.L) ? e[j] * 0.5f * __expf(0.5f * lv[j]) : 0.f;
                         dmu[j] += dz[j];
                         dlv[j] += dz[j] * ef;
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {  // columns >= L of the latent tiles carry no gradient (dz's column L is db4)
+                        dmu[j] = (4 * q + j < a.L) ? dmu[j] : 0.f;
+                        dlv[j] = (4 * q + j < a.L) ? dlv[j] : 0.f;
+                    }
+                    dmlb = pack2(dmu, dlv);
+                    *ws_ptr(tile, p) = __builtin_bit_cast(u32x4, dmlb);  // sweep 2 continues from here
                 }
+                // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w),  dW3~ += dml^T h2 (wave w -> out tile
+                // w >> 2, in tile w & 3)
+                launder(cc, qq);
+                st_op<2>(st, lrow, 4, 0, qq, dmlb);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {  // columns >= L of the latent tiles carry no gradient (dz's column L is db4)
-                    dmu[j] = (4 * q + j < a.L) ? dmu[j] : 0.f;
-                    dlv[j] = (4 * q + j < a.L) ? dlv[j] : 0.f;
-                }
-                dmlb = pack2(dmu, dlv);
-            }
-            // ================================================================ B: encoder backward
-            launder(cc, qq);
-            // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w),  dW3~ += dml^T h2 (wave w -> out tile w >> 2,
-            // in tile w & 3)
-            st_op<2>(st, lrow, 4, 0, qq, dmlb);
+                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 9, kb, qq, h2q[kb]);
+                if (two && p == 0) e = ld_lat(a.eps[1]);  // the next pass's eps arrives under this round
+                __syncthreads();
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 9, kb, qq, h2b[kb]);
-            __syncthreads();
+                for (int k2 = 0; k2 < TILE_ROWS / 64; ++k2) {  // two k-blocks per batch of reads
+                    __builtin_amdgcn_sched_barrier(0);
+                    Op fa4[2], fb4[2], fa3[2], fb3[2];
 #pragma unroll
-            for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
-                if (own4 && !skip_dec) {
-                    const Op fa = st_frag(st, w, kb, 16 * qq + cc);
-                    const Op fb = st_frag(st, 8, kb, 16 * qq + cc);
-                    acc4 = VPC_MFMA_BF(fa, fb, acc4);
-                }
-                const Op fa3 = st_frag(st, 4 + (w >> 2), kb, 16 * qq + cc);
-                const Op fb3 = st_frag(st, 9 + (w & 3), kb, 16 * qq + cc);
-                acc3 = VPC_MFMA_BF(fa3, fb3, acc3);
-            }
-            STP(8);
-            VPC_CUT();
-            launder(cc, qq);
-            // ---------------- dh2 = relu'(h2) * (W3~^T dml)
-            Op dh2b[2];
-            {
-                f32x4 hprev = zero4();
-                const Op din[1] = {dmlb};
-                c_layer_T<64, 1, H2T, 2>(W3, din, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                    const BfOp hp = {h2b[mt >> 1], h2b[mt >> 1]};
-                    const f32x4 h = bf_gate(acc, hp, mt & 1);
-                    if (mt & 1) dh2b[mt >> 1] = pack2(hprev, h);
-                    hprev = h;
-                });
-            }
-            // ---------------- R4: dW2~ += dh2^T h1   (owner: wave w < 7 -> in tile w, all 4 out tiles)
-            __syncthreads();
+                    for (int i = 0; i < 2; ++i) {
+                        const int kb = 2 * k2 + i;
+                        fa4[i] = st_frag(st, w & 3, kb, 16 * qq + cc);
+                        fb4[i] = st_frag(st, 8, kb, 16 * qq + cc);
+                        fa3[i] = st_frag(st, 4 + (w >> 2), kb, 16 * qq + cc);
+                        fb3[i] = st_frag(st, 9 + (w & 3), kb, 16 * qq + cc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dh2b[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, h1b[kb]);
-            __syncthreads();
-            if (own2) {
-#pragma unroll
-                for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
-                    asm volatile("" ::: "memory");
-                    const Op fb = st_frag(st, 8 + w, kb, 16 * qq + cc);
-#pragma unroll
-                    for (int mt = 0; mt < H2T; ++mt) {
-                        const Op fa = st_frag(st, mt, kb, 16 * qq + cc);
-                        acc2[mt] = VPC_MFMA_BF(fa, fb, acc2[mt]);
+                    for (int i = 0; i < 2; ++i) {
+                        if (own4) acc4 = VPC_MFMA_BF(fa4[i], fb4[i], acc4);
+                        acc3 = VPC_MFMA_BF(fa3[i], fb3[i], acc3);
                     }
                 }
-            }
-            STP(9);
-            VPC_CUT();
-            launder(cc, qq);
-            // ---------------- dh1 = relu'(h1) * (W2~^T dh2)
-            Op dh1b[4];
-            {
-                f32x4 hprev = zero4();
-                c_layer_T<128, 2, H1T, H2T>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                    const BfOp hp = {h1b[mt >> 1], h1b[mt >> 1]};
-                    const f32x4 h = bf_gate(acc, hp, mt & 1);
-                    if (mt & 1) dh1b[mt >> 1] = pack2(hprev, h);
-                    else if (mt + 1 == H1T) dh1b[mt >> 1] = pack2(h, zero4());
-                    hprev = h;
-                });
-            }
-            // ---------------- R5: dW1 += dh1^T (x * mask)  (owner: wave w -> in tile w, all 7 out tiles);  db1 += dh1^T 1
-            // (wave w < 7 -> out tile w).  x * mask is read again (L2) and staged by the owner of the row.
-            Op xb[(DT + 1) / 2];
-            {
-                f32x4 xprev = zero4();
+                if (two) {  // (current, other) <- (other, current)
+                    f32x4 t4;
+                    t4 = muQ; muQ = muP; muP = t4;
+                    t4 = lvQ; lvQ = lvP; lvP = t4;
 #pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const f32x4 xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (vo + col_off(t)), 0, 0));
-                    const uint32_t mw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rmA, vo + col_off(t), 0, 0);
-                    const uint32_t vm = opaque_mask(t < DT / 2 || 16 * t + 4 * q + 3 < a.d);
-                    const f32x4 xi = xr * mask_to_f32(mw & vm);
-                    if (t & 1) xb[t >> 1] = pack2(xprev, xi);
-                    else if (t + 1 == DT) xb[t >> 1] = pack2(xi, zero4());
-                    xprev = xi;
+                    for (int t = 0; t < DT; ++t) { const uint32_t u = mw0[t]; mw0[t] = mw1[t]; mw1[t] = u; }
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) { const Op o = h2q[kb]; h2q[kb] = h2p[kb]; h2p[kb] = o; }
                 }
+                STP(8);
             }
-            __syncthreads();
+        }
+        // ---------------- decoder partial block, dW3 and the loss terms
+        {
+            float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
+            const int hi = w >> 2;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dh1b[kb]);
+            for (int nt = 0; nt < H1T; ++nt)
 #pragma unroll
-            for (int kb = 0; kb < (DT + 1) / 2; ++kb) st_op<DT>(st, lrow, 7, kb, qq, xb[kb]);
-            __syncthreads();
+                for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = own6 ? acc6[nt][j] : 0.f;
 #pragma unroll
-            for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
-                asm volatile("" ::: "memory");
-                if (own2) accb = VPC_MFMA_BF(st_frag(st, w, kb, 16 * qq + cc), ones, accb);
-                if (own6) {
-                    const Op fb = st_frag(st, 7 + w, kb, 16 * qq + cc);
-                    Op fa = st_frag(st, 0, kb, 16 * qq + cc);
+            for (int i = 0; i < 4; ++i) {
+                float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
 #pragma unroll
-                    for (int mt = 0; mt < H1T; ++mt) {
-                        const Op fn = st_frag(st, mt + 1 < H1T ? mt + 1 : mt, kb, 16 * qq + cc);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc1[mt] = VPC_MFMA_BF(fa, fb, acc1[mt]);
-                        fa = fn;
-                    }
-                }
+                for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
             }
-            STP(10);
+            if (own4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
+            }
+            float* pe = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pe[(44 + j) * 64] = acc3[j];
+        }
+        const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
+#pragma unroll
+        for (int i = 0; i < LOSS_TERMS; ++i) {
+            const float v = wave_sum_dpp(s[i]);
+            if (lane == 0) red[w * LOSS_TERMS + i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < LOSS_TERMS) {
+            double t = 0.0;
+            for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+            a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
         }
     }
-    // ================================================================ partial blocks (layouts of vpc_layout.h) and loss terms
+    STP(9);
+    // ============================================================================================================ sweep 2
     {
+        f32x4 acc1[H1T], acc2[H2T], accb = zero4();
+#pragma unroll
+        for (int t = 0; t < H1T; ++t) acc1[t] = zero4();
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) acc2[t] = zero4();
+        const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const Op ones = __builtin_bit_cast(Op, ones_u);
+        for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+            const long row0 = (long)tile * TILE_ROWS;
+            const bool ok = row0 + lrow < a.B;
+            asm volatile("" ::: "memory");
+            int cc = c, qq = q;
+            launder(cc, qq);
+            // the tile's inputs, once: x, the mask words and the packed seeds of both passes (sweep 1 stored them from this very
+            // thread: same address, same lane)
+            f32x4 xr[DT];
+            uint32_t mw0[DT], mw1[DT];
+            load_x(row0, xr, cc, qq);
+            load_m(a.m[0], row0, mw0, cc, qq);
+            if (two) load_m(a.m[1], row0, mw1, cc, qq);
+            u32x4 s0 = *ws_ptr(tile, 0);
+            u32x4 s1 = {0u, 0u, 0u, 0u};
+            if (two) s1 = *ws_ptr(tile, 1);
+            clear_cols(mw0, qq);
+            if (two) clear_cols(mw1, qq);
+            for (int p = 0; p < a.npass; ++p) {
+                asm volatile("" ::: "memory");
+                launder(cc, qq);
+                const Op dmlb = __builtin_bit_cast(Op, s0);  // (current, other): swapped at the end of the pass
+                uint32_t (&mw)[DT] = mw0;
+                Op h1b[4], h2b[2];
+                {
+                    Op xb[KB1];
+                    f32x4 mu, lv;
+                    make_xb(xr, mw, xb, qq);
+                    enc_fwd(xb, h1b, h2b, mu, lv, cc, qq, ok);
+                }
+                STP(10);
+                launder(cc, qq);
+                // ---------------- dh2 = relu'(h2) * (W3~^T dml)
+                Op dh2b[2];
+                {
+                    f32x4 hprev = zero4();
+                    const Op din[1] = {dmlb};
+                    c_layer_T<64, 1, H2T, 2>(W3, din, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                        const BfOp hp = {h2b[mt >> 1], h2b[mt >> 1]};
+                        const f32x4 h = bf_gate(acc, hp, mt & 1);
+                        if (mt & 1) dh2b[mt >> 1] = pack2(hprev, h);
+                        hprev = h;
+                    });
+                }
+                // ---------------- R4: dW2~ += dh2^T h1   (owner: wave w < 7 -> in tile w, all 4 out tiles)
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dh2b[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, h1b[kb]);
+                __syncthreads();
+                if (own2) {
+#pragma unroll
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const Op fb = st_frag(st, 8 + w, kb, 16 * qq + cc);
+                        Op fa[H2T];
+#pragma unroll
+                        for (int mt = 0; mt < H2T; ++mt) fa[mt] = st_frag(st, mt, kb, 16 * qq + cc);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < H2T; ++mt) acc2[mt] = VPC_MFMA_BF(fa[mt], fb, acc2[mt]);
+                    }
+                }
+                STP(11);
+                VPC_CUT();
+                launder(cc, qq);
+                // ---------------- dh1 = relu'(h1) * (W2~^T dh2)
+                Op dh1b[4];
+                {
+                    f32x4 hprev = zero4();
+                    c_layer_T<128, 2, H1T, H2T>(W2, dh2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
+                        const BfOp hp = {h1b[mt >> 1], h1b[mt >> 1]};
+                        const f32x4 h = bf_gate(acc, hp, mt & 1);
+                        if (mt & 1) dh1b[mt >> 1] = pack2(hprev, h);
+                        else if (mt + 1 == H1T) dh1b[mt >> 1] = pack2(h, zero4());
+                        hprev = h;
+                    });
+                }
+                // ---------------- R5: dW1 += dh1^T (x * mask)  (owner: wave w -> in tile w, all 7 out tiles);  db1 += dh1^T 1
+                // (wave w < 7 -> out tile w)
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dh1b[kb]);
+                {
+                    Op xb2[KB1];  // x * mask once more (a few dozen VALU instead of 16 registers held since the encoder forward)
+                    make_xb(xr, mw, xb2, qq);
+#pragma unroll
+                    for (int kb = 0; kb < KB1; ++kb) st_op<DT>(st, lrow, 7, kb, qq, xb2[kb]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Op fb = st_frag(st, 7 + w, kb, 16 * qq + cc);
+                    const Op fw = st_frag(st, own2 ? w : 0, kb, 16 * qq + cc);  // dh1 tile w once more, for db1
+                    Op fa[H1T];
+#pragma unroll
+                    for (int mt = 0; mt < H1T; ++mt) fa[mt] = st_frag(st, mt, kb, 16 * qq + cc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (own2) accb = VPC_MFMA_BF(fw, ones, accb);
+#pragma unroll
+                    for (int mt = 0; mt < H1T; ++mt) acc1[mt] = VPC_MFMA_BF(fa[mt], fb, acc1[mt]);
+                }
+                if (two) {
+                    const u32x4 t4 = s0; s0 = s1; s1 = t4;
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) { const uint32_t u = mw0[t]; mw0[t] = mw1[t]; mw1[t] = u; }
+                }
+                STP(12);
+            }
+        }
         float* part = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
 #pragma unroll
         for (int mt = 0; mt < H1T; ++mt)
@@ -635,8 +776,6 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = own2 ? acc2[mt][j] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
         // db1[16 w + 4 q + j]: every column of the ones product holds the sum; lane c == 0 writes it
         if (c == 0 && own2) {
 #pragma unroll
@@ -644,41 +783,11 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         }
         if (w == 7 && lane < 16) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 112 + lane] = 0.f;
     }
-    {
-        float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
-        const int hi = w >> 2;
-#pragma unroll
-        for (int nt = 0; nt < H1T; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = own6 ? acc6[nt][j] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
-        }
-        if (own4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
-        }
-    }
-    const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
-#pragma unroll
-    for (int i = 0; i < LOSS_TERMS; ++i) {
-        const float v = wave_sum_dpp(s[i]);
-        if (lane == 0) red[w * LOSS_TERMS + i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < LOSS_TERMS) {
-        double t = 0.0;
-        for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
-        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
-    }
 #ifdef VPC_ABLATE
-    STP(11);
+    STP(13);
     if ((a.dbg & 64) && blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 3 == 0)
-        printf("step blk %d wave %d: prologue %llu E %llu g1g2 %llu out %llu R1 %llu dg2 %llu R2 %llu dg1+dz %llu R3 %llu R4 %llu R5 %llu epi %llu\n",
-               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11]);
+        printf("step blk %d wave %d: prologue %llu E1 %llu g1g2 %llu out %llu R1 %llu dg2 %llu R2 %llu dg1+dz %llu KL+R3 %llu epi1 %llu | E2 %llu dh2+R4 %llu dh1+R5 %llu epi2 %llu\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11], T[12], T[13]);
 #endif
 }
 
@@ -697,6 +806,11 @@ extern "C" int vpc_step_fused_applicable(long B, int d, int L, int npass) {
         if (atoi(e) == 0) return 0;  // A/B runs: the three-kernel form
     }
     return tile_shape(B, npass).small ? 0 : 1;
+}
+
+// floats of the caller-owned workspace vpc_step_fused_bf16 needs for a batch of B rows (the packed seeds between its sweeps)
+extern "C" long vpc_step_workspace_floats(long B) {
+    return B <= 0 ? 0 : ((B + TILE_ROWS - 1) / TILE_ROWS) * 2 * THREADS * 4;
 }
 
 extern "C" int vpc_step_layout_bf16(int d, int L, int* img_floats, int* lds_bytes) {
@@ -770,22 +884,27 @@ extern "C" int vpc_step_pack_weights_bf16(const float* flat_params, const int* p
 extern "C" int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uint8_t* const* mask,
                                    const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
                                    const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar,
-                                   float* partE, float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L,
-                                   void* stream) {
-    if (!x || !img_c || !mask || !cA || !cE || !eps || !partE || !partD || !loss_partials) return VPC_ERR_ARG;
+                                   float* partE, float* partD, double* loss_partials, float* workspace, int* nblocks_out,
+                                   long B, int d, int L, void* stream) {
+    if (!x || !img_c || !mask || !cA || !cE || !eps || !partE || !partD || !loss_partials || !workspace) return VPC_ERR_ARG;
+    if (!aligned16(workspace)) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
     if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
     if (!aligned16(x) || !aligned16(img_c)) return VPC_ERR_ARG;
     if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
     StepArgs a{};
-    a.x = x; a.img = img_c; a.eps_ml = eps_ml; a.partE = partE; a.partD = partD; a.loss_part = loss_partials;
+    a.x = x; a.img = img_c; a.eps_ml = eps_ml; a.partE = partE; a.partD = partD; a.loss_part = loss_partials; a.ws = workspace;
     a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
     a.B = B; a.d = d; a.L = L; a.npass = npass;
     for (int p = 0; p < npass; ++p) {
         if (!mask[p] || !eps[p]) return VPC_ERR_ARG;
         a.m[p] = mask[p]; a.mB[p] = maskB ? maskB[p] : nullptr; a.cA[p] = cA[p]; a.cE[p] = cE[p]; a.eps[p] = eps[p];
-        if ((uintptr_t)a.m[p] % 4 || (a.mB[p] && (uintptr_t)a.mB[p] % 4) || !aligned16(a.eps[p])) return VPC_ERR_ARG;
+        if ((uintptr_t)a.m[p] % 4 || !aligned16(a.eps[p])) return VPC_ERR_ARG;
     }
+    // the second loss mask of a pass (mE = mA (1 - mB)) must be the OTHER pass's mask - what the consistency term
+    // NLL(mask & ~mask_p) of src/models/VAE.py:444-446 needs: the kernel keeps both passes' mask words in registers and reads no third
+    for (int p = 0; p < npass; ++p)
+        if (a.mB[p] && (npass != 2 || a.mB[p] != a.m[1 - p])) return VPC_ERR_ARG;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);

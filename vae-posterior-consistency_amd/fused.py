@@ -134,6 +134,13 @@ class FusedTrainer:
         self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
         self._ws_B = (B, d)
 
+    def _step_ws(self, B):
+        """Workspace of the whole-step kernel (the packed seeds between its two sweeps)."""
+        n = ops.step_workspace_floats(B)
+        if getattr(self, "_ws_step", None) is None or self._ws_step.numel() < n:
+            self._ws_step = torch.empty(n, device=self.dev)
+        return self._ws_step
+
     def _timed(self, name, fn, *args):
         """Run one launch; with timers enabled bracket it with events on the launch stream."""
         if self.timers is None or self._timer_tick % self.timer_every or \
@@ -251,7 +258,7 @@ class FusedTrainer:
             # ---- plain bf16, throughput shape: encoder forward + decoder + loss + all backward in ONE launch
             nbE = nbD = self._timed("step_fused", ops.step_fused_bf16, x, self.img_c, masks, maskB, co["cA"], co["cE"], epss,
                                     eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,
-                                    self.partD, self.loss_part, dk, Ld)
+                                    self.partD, self.loss_part, self._step_ws(B), dk, Ld)
         else:
             # ---- forward (encoder), fused decoder + loss + decoder backward, encoder backward
             self._timed("encoder_fwd", ops.encoder_fwd, x, enc_img, masks, None, self.h1, self.h2, self.mean, self.logvar,

@@ -130,14 +130,18 @@ def step_pack_weights_bf16(flat, pack_idx_c, img_c):
           "vpc_step_pack_weights_bf16")
 
 
+def step_workspace_floats(B):
+    return int(lib().vpc_step_workspace_floats(int(B)))
+
+
 def step_fused_bf16(x, img_c, masks, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE, partD, loss_part,
-                    d, Ld):
+                    ws, d, Ld):
     """Whole step (encoder fwd + decoder + loss + all backward) in one launch; returns the number of partial blocks."""
     n = len(masks)
     nb = C.c_int(0)
     check(lib().vpc_step_fused_bf16(ptr(x), ptr(img_c), n, ptr_array(masks), ptr_array(maskB), farray(cA), farray(cE),
                                     ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml, inv_B, x_logvar, ptr(partE), ptr(partD),
-                                    ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_step_fused_bf16")
+                                    ptr(loss_part), ptr(ws), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_step_fused_bf16")
     return nb.value
 
 
