@@ -54,9 +54,22 @@ struct StepImg {
 constexpr int ST_FT = 15;                              // staging slots (16-feature tiles) per row
 constexpr int ST_DW = (TILE_ROWS / 8) * ST_FT * 64;    // 15 360 dwords
 constexpr int STEP_LDS = (StepImg::total + ST_DW + WAVES * LOSS_TERMS) * 4;
+// second staging area of sweep 2 (6 slots: dml 0-1, h2 2-5) in the LDS of the decoder layers' image, which that sweep does not read
+constexpr int ST2_FT = 6;
+static_assert((TILE_ROWS / 8) * ST2_FT * 64 <= StepImg::total - StepImg::oW4, "second staging area");
 static_assert(STEP_LDS <= 163840, "LDS budget");
 
 typedef bf16x8 Op;  // one MFMA operand: 8 k-slots per lane
+
+#ifndef VPC_STEP_PREFETCH
+#define VPC_STEP_PREFETCH 0  // 1: request a tile's inputs one tile ahead (see request_tile); measured, see profiles/r03_notes.md
+#endif
+constexpr bool PREFETCH = VPC_STEP_PREFETCH != 0;
+
+// Workgroup barrier for LDS hand-offs only: the wave's own LDS operations are complete (lgkmcnt(0)), global memory
+// operations stay in flight.  __syncthreads() is a fence as well - hipcc puts s_waitcnt vmcnt(0) in front of s_barrier - and
+// that made every staging round wait for the tile inputs requested one tile ahead (R1 29 k -> 51 k cycles).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ Op pack2(f32x4 t0, f32x4 t1) {
     const u32x4 h = {pk_bf16(t0[0], t0[1]), pk_bf16(t0[2], t0[3]), pk_bf16(t1[0], t1[1]), pk_bf16(t1[2], t1[3])};
@@ -80,7 +93,9 @@ __device__ __forceinline__ Op c_wfrag_T(const float* W, int mt, int kb, int lane
     const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     return __builtin_bit_cast(Op, h);
 }
-// forward layer: NT out tiles, KB k-blocks, fragments of tile mt + 1 requested before the MFMAs of tile mt
+// forward layer: NT out tiles, KB k-blocks.  ONE set of fragment registers: the fragments of tile mt + 1 are requested right
+// behind the MFMAs of tile mt (which have read theirs at issue) and arrive under the sink's VALU and the partner wave's work.
+// (A second set - next tile requested before the MFMAs - costs 4 KB registers per layer call, which this kernel does not have.)
 template <int KP, int KB, int NT, typename F>
 __device__ __forceinline__ void c_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink) {
     Op cur[KB];
@@ -88,16 +103,15 @@ __device__ __forceinline__ void c_layer_fwd(const float* W, const Op (&in)[KB], 
     for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, 0, kb, m, q);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        Op nxt[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) nxt[kb] = c_wfrag<KP>(W, mt + 1 < NT ? mt + 1 : mt, kb, m, q);
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc = zero4();
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = VPC_MFMA_BF(cur[kb], in[kb], acc);
-        sink(mt, acc);
+        if (mt + 1 < NT) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+            for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, mt + 1, kb, m, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sink(mt, acc);
     }
 }
 // dgrad layer: NT in-feature tiles, KB k-blocks over the image's ROWT 16-row tiles
@@ -111,31 +125,31 @@ __device__ __forceinline__ void c_layer_T(const float* W, const Op (&in)[KB], in
     for (int kb = 0; kb < KB; ++kb) cur[kb] = frag(0, kb);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        Op nxt[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) nxt[kb] = frag(mt + 1 < NT ? mt + 1 : mt, kb);
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc = zero4();
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = VPC_MFMA_BF(cur[kb], in[kb], acc);
-        sink(mt, acc);
+        if (mt + 1 < NT) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+            for (int kb = 0; kb < KB; ++kb) cur[kb] = frag(mt + 1, kb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sink(mt, acc);
     }
 }
 // ---- staging (bf_stage layout of vpc_bf16.h, FT = 15): operand of NT tiles whose first tile sits in slot `slot0`
-template <int NT>
+template <int NT, int FT = ST_FT>
 __device__ __forceinline__ void st_op(float* st, int row, int slot0, int kb, int q, Op op) {
     const u32x4 h = __builtin_bit_cast(u32x4, op);
-    const int o0 = bf_stage_off<ST_FT>(row, slot0 + 2 * kb, q);
+    const int o0 = bf_stage_off<FT>(row, slot0 + 2 * kb, q);
     *reinterpret_cast<u32x2*>(st + o0) = u32x2{h[0], h[1]};
     if (2 * kb + 1 < NT) *reinterpret_cast<u32x2*>(st + o0 + 64) = u32x2{h[2], h[3]};
 }
+template <int FT = ST_FT>
 __device__ __forceinline__ Op st_frag(const float* st, int slot, int kb, int lane) {
     const int g = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
-    const int off = bf_stage_off<ST_FT>(32 * kb + 4 * g + rr, slot, pp);
+    const int off = bf_stage_off<FT>(32 * kb + 4 * g + rr, slot, pp);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * ST_FT);
+    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * FT);
     const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     return __builtin_bit_cast(Op, h);
 }
@@ -160,8 +174,10 @@ struct StepArgs {
 
 #ifdef VPC_ABLATE
 #define STP(i) VPC_STAMP(i)
+#define LDS_BARRIER() do { if (!(a.dbg & 2)) lds_barrier(); } while (0)   // VPC_DEBUG & 2: timing without barriers (wrong results)
 #else
 #define STP(i) do {} while (0)
+#define LDS_BARRIER() lds_barrier()
 #endif
 
 // Two sweeps over the workgroup's tiles, so that only HALF of the gradient accumulators is live at any time (all 100 of them
@@ -198,9 +214,6 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mp) + row0 * a.d, 0,
                                                  rem > 0xffffffffL ? 0xffffffffu : (uint32_t)rem, 0x00020000);
     };
-    load_image<13>(lds, a.img, StepImg::total);
-    __syncthreads();
-    STP(0);
     const bool own6 = w < DT, own2 = w < H1T, own4 = w < H2T;
 
     // x rows of a tile in C layout (range-checked: rows past B read 0; columns past d read column 0 and are cleared through the
@@ -257,10 +270,56 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     };
     // workspace of the packed seeds: [tile][pass][thread] 16 bytes
     auto ws_ptr = [&](int tile, int p) { return reinterpret_cast<u32x4*>(a.ws) + ((long)tile * 2 + p) * THREADS + threadIdx.x; };
+    auto ld_lat = [&](const float* base, long row0) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
+        return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
+    };
+    // The inputs of a tile are REQUESTED one tile ahead, into the registers that hold them: x, the mask words of both passes
+    // (held as (current, other) and swapped at the end of a pass, so the request made during the last pass of the previous tile
+    // goes to the swapped places) and, sweep 1, eps of pass 0 / sweep 2, the packed seeds.  The first tile of sweep 1 is requested
+    // before the weight image, the first tile of sweep 2 before sweep 1's partial-block stores; without this every tile started
+    // with all 8 waves waiting on an HBM burst of ~100 KB per CU that every CU issues at the same time.
+    f32x4 xr[DT];
+    uint32_t mw0[DT], mw1[DT];
+    auto request_tile = [&](int tile, bool swapped) {
+        const long r0 = (long)tile * TILE_ROWS;
+        load_x(r0, xr, c, q);
+        if (!two) load_m(a.m[0], r0, mw0, c, q);
+        else if (swapped) { load_m(a.m[0], r0, mw1, c, q); load_m(a.m[1], r0, mw0, c, q); }
+        else { load_m(a.m[0], r0, mw0, c, q); load_m(a.m[1], r0, mw1, c, q); }
+    };
+    // prologue: the weight image's loads are issued first (one round: 13 x 16 bytes per thread), then the first tile's inputs;
+    // the image is written to LDS as soon as ITS loads have returned (vmcnt counts in issue order: the younger tile requests
+    // stay in flight)
+    f32x4 e = zero4();
+    {
+        constexpr int U = 13;
+        static_assert(U * THREADS * 4 >= StepImg::total, "one round of image loads");
+        f32x4 iv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (u * THREADS + (int)threadIdx.x) * 4;
+            iv[u] = *reinterpret_cast<const f32x4*>(a.img + (i < StepImg::total ? i : 0));
+        }
+        if (PREFETCH && (int)blockIdx.x < a.ntiles) {
+            request_tile(blockIdx.x, false);
+            e = ld_lat(a.eps[0], (long)blockIdx.x * TILE_ROWS);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (u * THREADS + (int)threadIdx.x) * 4;
+            if (i < StepImg::total) *reinterpret_cast<f32x4*>(lds + i) = iv[u];
+        }
+    }
+    if (!two) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) mw1[t] = 0u;
+    }
+    lds_barrier();
+    STP(0);
 
     // ============================================================================================================ sweep 1
     {
-        f32x4 acc6[H1T], acc5[H2T], acc4 = zero4(), acc3 = zero4();
+        f32x4 acc6[H1T], acc5[H2T], acc4 = zero4();
 #pragma unroll
         for (int t = 0; t < H1T; ++t) acc6[t] = zero4();
 #pragma unroll
@@ -272,42 +331,30 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
             const long row0 = (long)tile * TILE_ROWS;
             const bool ok = row0 + lrow < a.B;
-            const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, row0, a.B, a.d);
-            auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
-                return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), lrow, 16, 4 * q);
-            };
             asm volatile("" ::: "memory");  // the weight image never changes: keep LDS weight reads inside the tile
             int cc = c, qq = q;
             launder(cc, qq);
-            // ---------------- the tile's inputs: read ONCE and kept in registers for both passes of this sweep - x (32 registers),
-            // the mask words of both passes (16) and eps (8).  (Re-reading them per phase from L2 does not work: 32 workgroups
-            // per XCD stream 100 KB each through a 4 MB L2 beside partial blocks and scratch - measured 390 MB fetched per
-            // launch with per-phase re-reads.)
             // Everything that differs between the passes is held as a (current, other) pair and SWAPPED at the end of a pass:
-            // selecting per pass (p == 0 ? q : p) makes a second live copy of whatever is selected.
-            f32x4 xr[DT];
-            uint32_t mw0[DT], mw1[DT];
-            load_x(row0, xr, cc, qq);
-            load_m(a.m[0], row0, mw0, cc, qq);
-            if (two) load_m(a.m[1], row0, mw1, cc, qq);
-            else {
-#pragma unroll
-                for (int t = 0; t < DT; ++t) mw1[t] = 0u;
+            // selecting per pass (p == 0 ? q : p) makes a second live copy of whatever is selected.  x (32 registers), the mask
+            // words of both passes (16) and eps (4) were requested one tile ahead (request_tile) and stay in registers for both
+            // passes of this sweep.  (Re-reading them per phase from L2 does not work: 32 workgroups per XCD stream 100 KB each
+            // through a 4 MB L2 beside partial blocks - measured 390 MB fetched per launch with per-phase re-reads.)
+            if (!PREFETCH) {
+                request_tile(tile, false);
+                e = ld_lat(a.eps[0], row0);
             }
-            f32x4 e = ld_lat(a.eps[0]);
             clear_cols(mw0, qq);
             if (two) clear_cols(mw1, qq);
-            // ---------------- E: statistics and packed h2 of both passes
+            // ---------------- E: statistics of both passes
             f32x4 muQ, lvQ, muP = zero4(), lvP = zero4();
-            Op h2q[2], h2p[2];
             {
-                Op xb[KB1], h1b[4];
+                Op xb[KB1], h1b[4], h2b[2];
                 make_xb(xr, mw0, xb, qq);
-                enc_fwd(xb, h1b, h2q, muQ, lvQ, cc, qq, ok);
+                enc_fwd(xb, h1b, h2b, muQ, lvQ, cc, qq, ok);
                 if (two) {
                     launder(cc, qq);
                     make_xb(xr, mw1, xb, qq);
-                    enc_fwd(xb, h1b, h2p, muP, lvP, cc, qq, ok);
+                    enc_fwd(xb, h1b, h2b, muP, lvP, cc, qq, ok);
                 }
             }
             STP(1);
@@ -367,7 +414,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     // staging slots (tile mt -> slot mt, 8 bytes per lane and tile) instead of growing to 16 registers across
                     // the loop; the dgrad below reads the lane's own chunks back.  The barrier: every wave is past the reads of
                     // the previous staging round.
-                    __syncthreads();
+                    LDS_BARRIER();
                     {
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         constexpr float NLOG2E = -1.4426950408889634f;
@@ -421,10 +468,12 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     STP(3);
                     VPC_CUT();
                     launder(cc, qq);
+                    // x and the mask words are dead after the last pass's output tiles: the next tile's are requested now
+                    if (PREFETCH && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) request_tile(tile + (int)gridDim.x, two);
                     // ---------------- R1: dW6~ += dpre^T g2   (owner: wave w -> out tile w, all 7 in tiles)
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, g2b[kb]);
-                    __syncthreads();
+                    LDS_BARRIER();
                     // (all fragment reads of a k-block are in flight before its first MFMA: issued one by one in front of their
                     // MFMA every product waits a full LDS round trip - the rounds were 4-6 k cycles of that)
                     if (own6) {
@@ -432,12 +481,17 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                         for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
                             __builtin_amdgcn_sched_barrier(0);
                             const Op fa = st_frag(st, w, kb, 16 * qq + cc);
-                            Op fb[H1T];
+                            Op fb[4];  // in tiles 0-3, then 4-6: two batches of reads (registers)
 #pragma unroll
-                            for (int nt = 0; nt < H1T; ++nt) fb[nt] = st_frag(st, 8 + nt, kb, 16 * qq + cc);
+                            for (int nt = 0; nt < 4; ++nt) fb[nt] = st_frag(st, 8 + nt, kb, 16 * qq + cc);
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int nt = 0; nt < H1T; ++nt) acc6[nt] = VPC_MFMA_BF(fa, fb[nt], acc6[nt]);
+                            for (int nt = 0; nt < 4; ++nt) acc6[nt] = VPC_MFMA_BF(fa, fb[nt], acc6[nt]);
+#pragma unroll
+                            for (int nt = 4; nt < H1T; ++nt) fb[nt - 4] = st_frag(st, 8 + nt, kb, 16 * qq + cc);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int nt = 4; nt < H1T; ++nt) acc6[nt] = VPC_MFMA_BF(fa, fb[nt - 4], acc6[nt]);
                         }
                     }
                     STP(4);
@@ -472,12 +526,12 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     Op g1b[2];
                     uint32_t gm1;
                     make_g1(g1b, gm1);
-                    __syncthreads();
+                    LDS_BARRIER();
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dg2b[kb]);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 8, kb, qq, g1b[kb]);
-                    __syncthreads();
+                    LDS_BARRIER();
                     {
                         const int nt5 = w & 3, mt5 = 4 * (w >> 2);
 #pragma unroll
@@ -508,14 +562,13 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                         c_layer_T<32, 2, 1, H2T>(W4, dg1b, 16 * qq + cc, [&](int, f32x4 acc) { dz = acc; });
                     }
                     // R3's decoder operands (the seeds and h2 follow below)
-                    __syncthreads();
+                    LDS_BARRIER();
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dg1b[kb]);
                     st_op<1>(st, lrow, 8, 0, qq, zb);
                 }
                 STP(7);
                 // ---------------- KL terms, their seeds, total seeds on (mean | logvar)
-                Op dmlb;
                 {
                     f32x4 dmu, dlv;
                     const float b0 = (p == 0) ? a.bq : a.bp;
@@ -537,7 +590,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     }
                     if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
                     if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
-                        const f32x4 e3 = ld_lat(a.eps_ml);
+                        const f32x4 e3 = ld_lat(a.eps_ml, row0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool live = ok && 4 * q + j < a.L;
@@ -568,35 +621,23 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                         dmu[j] = (4 * q + j < a.L) ? dmu[j] : 0.f;
                         dlv[j] = (4 * q + j < a.L) ? dlv[j] : 0.f;
                     }
-                    dmlb = pack2(dmu, dlv);
-                    *ws_ptr(tile, p) = __builtin_bit_cast(u32x4, dmlb);  // sweep 2 continues from here
+                    *ws_ptr(tile, p) = __builtin_bit_cast(u32x4, pack2(dmu, dlv));  // sweep 2 continues from here
                 }
-                // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w),  dW3~ += dml^T h2 (wave w -> out tile
-                // w >> 2, in tile w & 3)
+                // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w)
                 launder(cc, qq);
-                st_op<2>(st, lrow, 4, 0, qq, dmlb);
+                // the next pass's (or the next tile's first pass's) eps arrives under this round
+                if (two && p == 0) e = ld_lat(a.eps[1], row0);
+                else if (PREFETCH && tile + (int)gridDim.x < a.ntiles) e = ld_lat(a.eps[0], row0 + (long)gridDim.x * TILE_ROWS);
+                LDS_BARRIER();
+                if (own4) {
+                    Op fa4[TILE_ROWS / 32], fb4[TILE_ROWS / 32];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 9, kb, qq, h2q[kb]);
-                if (two && p == 0) e = ld_lat(a.eps[1]);  // the next pass's eps arrives under this round
-                __syncthreads();
-#pragma unroll
-                for (int k2 = 0; k2 < TILE_ROWS / 64; ++k2) {  // two k-blocks per batch of reads
-                    __builtin_amdgcn_sched_barrier(0);
-                    Op fa4[2], fb4[2], fa3[2], fb3[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int kb = 2 * k2 + i;
-                        fa4[i] = st_frag(st, w & 3, kb, 16 * qq + cc);
-                        fb4[i] = st_frag(st, 8, kb, 16 * qq + cc);
-                        fa3[i] = st_frag(st, 4 + (w >> 2), kb, 16 * qq + cc);
-                        fb3[i] = st_frag(st, 9 + (w & 3), kb, 16 * qq + cc);
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                        fa4[kb] = st_frag(st, w, kb, 16 * qq + cc);
+                        fb4[kb] = st_frag(st, 8, kb, 16 * qq + cc);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (own4) acc4 = VPC_MFMA_BF(fa4[i], fb4[i], acc4);
-                        acc3 = VPC_MFMA_BF(fa3[i], fb3[i], acc3);
-                    }
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) acc4 = VPC_MFMA_BF(fa4[kb], fb4[kb], acc4);
                 }
                 if (two) {  // (current, other) <- (other, current)
                     f32x4 t4;
@@ -604,12 +645,12 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     t4 = lvQ; lvQ = lvP; lvP = t4;
 #pragma unroll
                     for (int t = 0; t < DT; ++t) { const uint32_t u = mw0[t]; mw0[t] = mw1[t]; mw1[t] = u; }
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) { const Op o = h2q[kb]; h2q[kb] = h2p[kb]; h2p[kb] = o; }
                 }
                 STP(8);
             }
         }
+        // sweep 2's first tile is requested before this sweep's partial-block stores
+        if (PREFETCH && (int)blockIdx.x < a.ntiles) request_tile(blockIdx.x, false);
         // ---------------- decoder partial block, dW3 and the loss terms
         {
             float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
@@ -628,9 +669,6 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
             }
-            float* pe = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pe[(44 + j) * 64] = acc3[j];
         }
         const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
 #pragma unroll
@@ -638,7 +676,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
             const float v = wave_sum_dpp(s[i]);
             if (lane == 0) red[w * LOSS_TERMS + i] = v;
         }
-        __syncthreads();
+        LDS_BARRIER();
         if (threadIdx.x < LOSS_TERMS) {
             double t = 0.0;
             for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
@@ -648,29 +686,32 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     STP(9);
     // ============================================================================================================ sweep 2
     {
-        f32x4 acc1[H1T], acc2[H2T], accb = zero4();
+        f32x4 acc1[H1T], acc2[H2T], accb = zero4(), acc3 = zero4();
+        float* st2 = lds + StepImg::oW4;  // (every wave is past sweep 1's last read of W4 .. W6: the barrier of the loss reduction)
 #pragma unroll
         for (int t = 0; t < H1T; ++t) acc1[t] = zero4();
 #pragma unroll
         for (int t = 0; t < H2T; ++t) acc2[t] = zero4();
         const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
         const Op ones = __builtin_bit_cast(Op, ones_u);
+        u32x4 s0 = {0u, 0u, 0u, 0u}, s1 = {0u, 0u, 0u, 0u};
+        if (PREFETCH && (int)blockIdx.x < a.ntiles) {
+            s0 = *ws_ptr(blockIdx.x, 0);
+            if (two) s1 = *ws_ptr(blockIdx.x, 1);
+        }
         for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
             const long row0 = (long)tile * TILE_ROWS;
             const bool ok = row0 + lrow < a.B;
             asm volatile("" ::: "memory");
             int cc = c, qq = q;
             launder(cc, qq);
-            // the tile's inputs, once: x, the mask words and the packed seeds of both passes (sweep 1 stored them from this very
-            // thread: same address, same lane)
-            f32x4 xr[DT];
-            uint32_t mw0[DT], mw1[DT];
-            load_x(row0, xr, cc, qq);
-            load_m(a.m[0], row0, mw0, cc, qq);
-            if (two) load_m(a.m[1], row0, mw1, cc, qq);
-            u32x4 s0 = *ws_ptr(tile, 0);
-            u32x4 s1 = {0u, 0u, 0u, 0u};
-            if (two) s1 = *ws_ptr(tile, 1);
+            if (!PREFETCH) {
+                request_tile(tile, false);
+                s0 = *ws_ptr(tile, 0);
+                if (two) s1 = *ws_ptr(tile, 1);
+            }
+            // x and the mask words were requested one tile ahead (request_tile); the packed seeds of both passes come back from
+            // the workspace (sweep 1 stored them from this very thread: same address, same lane)
             clear_cols(mw0, qq);
             if (two) clear_cols(mw1, qq);
             for (int p = 0; p < a.npass; ++p) {
@@ -678,12 +719,18 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                 launder(cc, qq);
                 const Op dmlb = __builtin_bit_cast(Op, s0);  // (current, other): swapped at the end of the pass
                 uint32_t (&mw)[DT] = mw0;
-                Op h1b[4], h2b[2];
+                Op xb[KB1], h1b[4], h2b[2];
                 {
-                    Op xb[KB1];
                     f32x4 mu, lv;
                     make_xb(xr, mw, xb, qq);
                     enc_fwd(xb, h1b, h2b, mu, lv, cc, qq, ok);
+                }
+                // x, the mask words and the seed registers are dead from here in the last pass (xb is kept for R5): the next
+                // tile's inputs are requested now and arrive under the two staging rounds
+                if (PREFETCH && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) {
+                    const int nt = tile + (int)gridDim.x;
+                    request_tile(nt, two);
+                    if (two) { s0 = *ws_ptr(nt, 1); s1 = *ws_ptr(nt, 0); } else { s0 = *ws_ptr(nt, 0); }
                 }
                 STP(10);
                 launder(cc, qq);
@@ -699,13 +746,27 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                         hprev = h;
                     });
                 }
-                // ---------------- R4: dW2~ += dh2^T h1   (owner: wave w < 7 -> in tile w, all 4 out tiles)
-                __syncthreads();
+                // ---------------- R4: dW2~ += dh2^T h1   (owner: wave w < 7 -> in tile w, all 4 out tiles);  dW3~ += dml^T h2 (wave w ->
+                // out tile w >> 2, in tile w & 3) from the second staging area
+                LDS_BARRIER();
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) st_op<H2T>(st, lrow, 0, kb, qq, dh2b[kb]);
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, h1b[kb]);
-                __syncthreads();
+                st_op<2, ST2_FT>(st2, lrow, 0, 0, qq, dmlb);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) st_op<H2T, ST2_FT>(st2, lrow, 2, kb, qq, h2b[kb]);
+                LDS_BARRIER();
+                {
+                    Op fa3[TILE_ROWS / 32], fb3[TILE_ROWS / 32];
+#pragma unroll
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
+                        fa3[kb] = st_frag<ST2_FT>(st2, w >> 2, kb, 16 * qq + cc);
+                        fb3[kb] = st_frag<ST2_FT>(st2, 2 + (w & 3), kb, 16 * qq + cc);
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < TILE_ROWS / 32; ++kb) acc3 = VPC_MFMA_BF(fa3[kb], fb3[kb], acc3);
+                }
                 if (own2) {
 #pragma unroll
                     for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
@@ -736,16 +797,12 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                 }
                 // ---------------- R5: dW1 += dh1^T (x * mask)  (owner: wave w -> in tile w, all 7 out tiles);  db1 += dh1^T 1
                 // (wave w < 7 -> out tile w)
-                __syncthreads();
+                LDS_BARRIER();
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dh1b[kb]);
-                {
-                    Op xb2[KB1];  // x * mask once more (a few dozen VALU instead of 16 registers held since the encoder forward)
-                    make_xb(xr, mw, xb2, qq);
 #pragma unroll
-                    for (int kb = 0; kb < KB1; ++kb) st_op<DT>(st, lrow, 7, kb, qq, xb2[kb]);
-                }
-                __syncthreads();
+                for (int kb = 0; kb < KB1; ++kb) st_op<DT>(st, lrow, 7, kb, qq, xb[kb]);
+                LDS_BARRIER();
 #pragma unroll
                 for (int kb = 0; kb < TILE_ROWS / 32; ++kb) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -776,6 +833,8 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = own2 ? acc2[mt][j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
         // db1[16 w + 4 q + j]: every column of the ones product holds the sum; lane c == 0 writes it
         if (c == 0 && own2) {
 #pragma unroll
