@@ -9,7 +9,7 @@ SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_dec8.hip", "vpc_step.hip", "vpc_misc.
 HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h", "vpc_dec_args.h", "vpc_bf16.h", "../../include/vpc.h"]
 LIB = os.path.join(HERE, "libvpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-variable",
+FLAGS = os.environ.get("VPC_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"]
 
 

@@ -26,6 +26,7 @@
 #include "vpc_bf16.h"
 #include "vpc_dec_args.h"
 #include <cstring>
+#include <type_traits>
 
 namespace vpc {
 
@@ -96,22 +97,51 @@ __device__ __forceinline__ Op c_wfrag_T(const float* W, int mt, int kb, int lane
 // forward layer: NT out tiles, KB k-blocks.  ONE set of fragment registers: the fragments of tile mt + 1 are requested right
 // behind the MFMAs of tile mt (which have read theirs at issue) and arrive under the sink's VALU and the partner wave's work.
 // (A second set - next tile requested before the MFMAs - costs 4 KB registers per layer call, which this kernel does not have.)
-template <int KP, int KB, int NT, typename F>
+template <int KP, int KB, int NT, bool DB = false, typename F>
 __device__ __forceinline__ void c_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink) {
     Op cur[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, 0, kb, m, q);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
+        Op nxt[DB ? KB : 1];  // DB: a second set, requested BEFORE this tile's MFMAs (where the registers are there)
+        if (DB && mt + 1 < NT) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) nxt[DB ? kb : 0] = c_wfrag<KP>(W, mt + 1, kb, m, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x4 acc = zero4();
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = VPC_MFMA_BF(cur[kb], in[kb], acc);
         if (mt + 1 < NT) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, mt + 1, kb, m, q);
+            for (int kb = 0; kb < KB; ++kb) cur[kb] = DB ? nxt[DB ? kb : 0] : c_wfrag<KP>(W, mt + 1, kb, m, q);
         }
         __builtin_amdgcn_sched_barrier(0);
         sink(mt, acc);
+    }
+}
+// the same for TWO inputs (the two passes of a tile): every weight fragment feeds two independent MFMA chains - half the LDS
+// fragment reads per product and a second chain in flight while the first one's result is on its way
+template <int KP, int KB, int NT, typename F>
+__device__ __forceinline__ void c_layer_fwd2(const float* W, const Op (&in0)[KB], const Op (&in1)[KB], int m, int q, F&& sink) {
+    Op cur[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, 0, kb, m, q);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            acc0 = VPC_MFMA_BF(cur[kb], in0[kb], acc0);
+            acc1 = VPC_MFMA_BF(cur[kb], in1[kb], acc1);
+        }
+        if (mt + 1 < NT) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) cur[kb] = c_wfrag<KP>(W, mt + 1, kb, m, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sink(mt, acc0, acc1);
     }
 }
 // dgrad layer: NT in-feature tiles, KB k-blocks over the image's ROWT 16-row tiles
@@ -169,6 +199,7 @@ struct StepArgs {
     float bq, bp, cr, wml, inv_B, x_logvar;
     long B;
     int d, L, npass, ntiles;
+    int stagger;  // start delay of workgroup group (blockIdx.x / 8) % 8, in units of 64 clocks per group (0 = none)
     int dbg;  // diagnostic build only (-DVPC_ABLATE): 64 = print the phase stamps of workgroup 100
 };
 
@@ -188,7 +219,7 @@ struct StepArgs {
 //           R3 (dW4, dW3); the packed seeds (dmean | dlogvar: 16 bytes per lane) go to a small workspace (8 MB at B = 65 536)
 //   sweep 2 (encoder accumulators dW1, dW2, db1: 48 registers): per tile and pass  E again (h1, h2: the recompute costs ~60
 //           bf16 MFMAs per wave), seeds back from the workspace, dh2, R4, dh1, R5.
-template <int DT>
+template <int DT, bool STAGED>
 __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -208,6 +239,13 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     const int lrow = w * 16 + c;
     const bool two = a.npass == 2;
     constexpr int KB1 = (DT + 1) / 2;
+    // Staggered start: all workgroups of a launch otherwise run in lockstep - every CU requests its 100 KB tile at the same
+    // moment, then every CU computes while HBM idles.  Group g = (blockIdx.x / 8) % 8 (four CUs of every XCD) starts g * stagger
+    // * 64 clocks late, which spreads the bursts of the whole launch over time.
+    if (a.stagger > 0) {
+        const int g = ((int)blockIdx.x >> 3) & 7;
+        for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 
     auto mask_rsrc = [&](const uint8_t* mp, long row0) {
         const long rem = (a.B - row0) * (long)a.d;
@@ -249,24 +287,48 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         }
     };
     // encoder forward of one pass from its packed input: h1 / h2 as packed operands, (mean | logvar) tiles
-    auto enc_fwd = [&](const Op (&xb)[KB1], Op (&h1b)[4], Op (&h2b)[2], f32x4& mu, f32x4& lv, int cc, int qq, bool ok) {
+    auto enc_fwd = [&](auto db, const Op (&xb)[KB1], Op (&h1b)[4], Op (&h2b)[2], f32x4& mu, f32x4& lv, int cc, int qq, bool ok) {
+        constexpr bool DB = decltype(db)::value;
         f32x4 hprev = zero4();
-        c_layer_fwd<128, KB1, H1T>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
+        c_layer_fwd<128, KB1, H1T, DB>(W1, xb, cc, qq, [&](int mt, f32x4 acc) {
             const f32x4 h = relu4(acc + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq));
             if (mt & 1) h1b[mt >> 1] = pack2(hprev, h);
             else if (mt + 1 == H1T) h1b[mt >> 1] = pack2(h, zero4());
             hprev = h;
         });
-        c_layer_fwd<128, 4, H2T>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
+        c_layer_fwd<128, 4, H2T, DB>(W2, h1b, cc, qq, [&](int mt, f32x4 acc) {
             const f32x4 h = relu4(acc);
             if (mt & 1) h2b[mt >> 1] = pack2(hprev, h);
             hprev = h;
         });
         f32x4 ml[2];
-        c_layer_fwd<64, 2, 2>(W3, h2b, cc, qq, [&](int mt, f32x4 acc) { ml[mt] = acc; });
+        c_layer_fwd<64, 2, 2, DB>(W3, h2b, cc, qq, [&](int mt, f32x4 acc) { ml[mt] = acc; });
         const uint32_t okm = opaque_mask(ok);  // rows past B: statistics 0 (as the range-checked workspace loads gave)
         mu = and4(ml[0], okm);
         lv = and4(ml[1], okm);
+    };
+    // both passes of a tile at once (sweep 1: only the statistics are wanted): two MFMA chains per weight fragment
+    auto enc_fwd2 = [&](const Op (&xb0)[KB1], const Op (&xb1)[KB1], f32x4& mu0, f32x4& lv0, f32x4& mu1, f32x4& lv1, int cc, int qq,
+                        bool ok) {
+        Op h1a[4], h1c[4], h2a[2], h2c[2];
+        f32x4 pa = zero4(), pc = zero4();
+        c_layer_fwd2<128, KB1, H1T>(W1, xb0, xb1, cc, qq, [&](int mt, f32x4 acc0, f32x4 acc1) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq);
+            const f32x4 ha = relu4(acc0 + bias), hc = relu4(acc1 + bias);
+            if (mt & 1) { h1a[mt >> 1] = pack2(pa, ha); h1c[mt >> 1] = pack2(pc, hc); }
+            else if (mt + 1 == H1T) { h1a[mt >> 1] = pack2(ha, zero4()); h1c[mt >> 1] = pack2(hc, zero4()); }
+            pa = ha; pc = hc;
+        });
+        c_layer_fwd2<128, 4, H2T>(W2, h1a, h1c, cc, qq, [&](int mt, f32x4 acc0, f32x4 acc1) {
+            const f32x4 ha = relu4(acc0), hc = relu4(acc1);
+            if (mt & 1) { h2a[mt >> 1] = pack2(pa, ha); h2c[mt >> 1] = pack2(pc, hc); }
+            pa = ha; pc = hc;
+        });
+        f32x4 ml0[2], ml1[2];
+        c_layer_fwd2<64, 2, 2>(W3, h2a, h2c, cc, qq, [&](int mt, f32x4 acc0, f32x4 acc1) { ml0[mt] = acc0; ml1[mt] = acc1; });
+        const uint32_t okm = opaque_mask(ok);
+        mu0 = and4(ml0[0], okm); lv0 = and4(ml0[1], okm);
+        mu1 = and4(ml1[0], okm); lv1 = and4(ml1[1], okm);
     };
     // workspace of the packed seeds: [tile][pass][thread] 16 bytes
     auto ws_ptr = [&](int tile, int p) { return reinterpret_cast<u32x4*>(a.ws) + ((long)tile * 2 + p) * THREADS + threadIdx.x; };
@@ -287,9 +349,86 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         else if (swapped) { load_m(a.m[0], r0, mw1, c, q); load_m(a.m[1], r0, mw0, c, q); }
         else { load_m(a.m[0], r0, mw0, c, q); load_m(a.m[1], r0, mw1, c, q); }
     };
+    // ---- tile inputs THROUGH LDS (obs_dim = 128): fully coalesced global loads -> the staging area (free at the start of a
+    // tile) -> the C-layout registers.  Loading straight into C layout (request_tile) makes every wave instruction touch 16
+    // rows: a tile is ~3 300 cache-line lookups per CU for 100 KB, 256 of every wave's 416 for the 4 KB of mask bytes, and
+    // the loads took 16-20 k cycles per tile whether they came from HBM or from cache (stamps, profiles/r03_notes.md): a fifth
+    // of the kernel with all 8 waves waiting.  Coalesced, a wave moves the same bytes in 14 instructions of full lines.
+    // Two COLUMN halves (features 0-63, then 64-127) of all 128 rows, 56 KB each: x 32 KB (16 granules of 16 bytes per row),
+    // the two masks 8 KB each (4 granules per row), eps of the first pass 8 KB (first half only); after a barrier every wave
+    // reads its rows' four tiles of that half - the same code for all waves.  Granules are XOR-swizzled by row (x: key row & 15,
+    // masks: key (row >> 1) & 3) so that the C-layout reads spread over the banks (x conflict-free, masks 2-way).
+    constexpr int SX = 0, SM0 = 8192, SM1 = 10240, SE0 = 12288;  // dword offsets inside the staging area
+    static_assert(SE0 + 2048 <= ST_DW, "staged tile inputs");
+    constexpr bool staged_in = STAGED;  // (instantiated for obs_dim == 128; other widths load straight into C layout)
+    auto stage_in = [&](int tile, bool with_eps, f32x4& ev) {
+        const long r0 = (long)tile * TILE_ROWS;
+        const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, r0, a.B, 128);
+        const __amdgpu_buffer_rsrc_t rm0 = mask_rsrc(a.m[0], r0), rm1 = mask_rsrc(a.m[two ? 1 : 0], r0);
+        f32x4 gx[4], gm0, gm1 = zero4(), ge = zero4();
+        auto issue = [&](int hc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gi = (4 * w + k) * 64 + lane;  // row gi >> 4, granule gi & 15 of this column half
+                gx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (gi >> 4) * 512 + hc * 256 + (gi & 15) * 16, 0, 0));
+            }
+            const int gi = w * 64 + lane;  // row gi >> 2, granule gi & 3
+            gm0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm0, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
+            if (two) gm1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm1, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
+            if (with_eps && hc == 0)
+                ge = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.eps[0], r0, a.B, 16), gi * 16, 0, 0));
+        };
+        issue(0);
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+            LDS_BARRIER();  // the staging area is free: every wave is past its reads of the previous round / half
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gi = (4 * w + k) * 64 + lane, row = gi >> 4, gc = gi & 15;
+                *reinterpret_cast<f32x4*>(st + SX + 4 * (row * 16 + (gc ^ (row & 15)))) = gx[k];
+            }
+            {
+                const int gi = w * 64 + lane, row = gi >> 2, gc = gi & 3;
+                const int o = 4 * (row * 4 + (gc ^ ((row >> 1) & 3)));
+                *reinterpret_cast<f32x4*>(st + SM0 + o) = gm0;
+                if (two) *reinterpret_cast<f32x4*>(st + SM1 + o) = gm1;
+                if (with_eps && hc == 0) *reinterpret_cast<f32x4*>(st + SE0 + 4 * gi) = ge;
+            }
+#ifdef VPC_ABLATE
+            if (hc == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STP(15); }
+#endif
+            if (hc == 0) issue(1);  // the second half's loads fly while the first half is read
+            LDS_BARRIER();
+            const int lr = 16 * w + c;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xr[4 * hc + t] = *reinterpret_cast<const f32x4*>(st + SX + 4 * (lr * 16 + ((4 * t + q) ^ c)));
+                const int mo = 4 * (lr * 4 + (t ^ ((c >> 1) & 3))) + q;
+                mw0[4 * hc + t] = __float_as_uint(st[SM0 + mo]);
+                if (two) mw1[4 * hc + t] = __float_as_uint(st[SM1 + mo]);
+            }
+            if (with_eps && hc == 0) ev = *reinterpret_cast<const f32x4*>(st + SE0 + 4 * (lr * 4 + q));
+        }
+    };
     // prologue: the weight image's loads are issued first (one round: 13 x 16 bytes per thread), then the first tile's inputs;
     // the image is written to LDS as soon as ITS loads have returned (vmcnt counts in issue order: the younger tile requests
     // stay in flight)
+    // One dword per 128-byte line of a tile's x / mask / eps rows, result unused: the next tile of sweep 1 is pulled into L2 / the
+    // Infinity Cache under the current tile, so that its real loads are cache hits instead of a cold HBM burst of ~100 KB per CU
+    // that every CU issues at the same moment (measured: ~9 k cycles per tile with all 8 waves waiting).  Unlike requests into
+    // registers (request_tile ahead of time) this costs two registers and two loads per thread.
+    auto touch = [&](int tl) -> uint32_t {
+        const long r0 = (long)tl * TILE_ROWS;
+        const int t = threadIdx.x;
+        uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(a.x, r0, a.B, a.d), t * 128 < TILE_ROWS * a.d * 4 ? t * 128 : 0, 0, 0);
+        const int which = t >> 7, ln = (t & 127) * 128;
+        if (which < 2) {
+            if (which < a.npass && ln < TILE_ROWS * a.d) v |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mask_rsrc(a.m[which], r0), ln, 0, 0);
+        } else if (which - 2 < a.npass && ln < TILE_ROWS * 64) {
+            v |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(a.eps[which - 2], r0, a.B, 16), ln, 0, 0);
+        }
+        return v;
+    };
     f32x4 e = zero4();
     {
         constexpr int U = 13;
@@ -339,7 +478,9 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
             // words of both passes (16) and eps (4) were requested one tile ahead (request_tile) and stay in registers for both
             // passes of this sweep.  (Re-reading them per phase from L2 does not work: 32 workgroups per XCD stream 100 KB each
             // through a 4 MB L2 beside partial blocks - measured 390 MB fetched per launch with per-phase re-reads.)
-            if (!PREFETCH) {
+            if (staged_in) {
+                stage_in(tile, true, e);
+            } else if (!PREFETCH) {
                 request_tile(tile, false);
                 e = ld_lat(a.eps[0], row0);
             }
@@ -348,15 +489,26 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
             // ---------------- E: statistics of both passes
             f32x4 muQ, lvQ, muP = zero4(), lvP = zero4();
             {
-                Op xb[KB1], h1b[4], h2b[2];
+                Op xb[KB1];
                 make_xb(xr, mw0, xb, qq);
-                enc_fwd(xb, h1b, h2b, muQ, lvQ, cc, qq, ok);
+#ifdef VPC_ABLATE
+                asm volatile("" ::"v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]));
+                STP(14);
+#endif
                 if (two) {
-                    launder(cc, qq);
-                    make_xb(xr, mw1, xb, qq);
-                    enc_fwd(xb, h1b, h2b, muP, lvP, cc, qq, ok);
+                    Op xbp[KB1];
+                    make_xb(xr, mw1, xbp, qq);
+                    enc_fwd2(xb, xbp, muQ, lvQ, muP, lvP, cc, qq, ok);
+                } else {
+                    Op h1b[4], h2b[2];
+                    enc_fwd(std::false_type{}, xb, h1b, h2b, muQ, lvQ, cc, qq, ok);
                 }
             }
+            uint32_t tv = 0;
+#ifdef VPC_ABLATE
+            if (!(a.dbg & 8))
+#endif
+            if (!PREFETCH && tile + (int)gridDim.x < a.ntiles) tv = touch(tile + (int)gridDim.x);
             STP(1);
             for (int p = 0; p < a.npass; ++p) {
                 asm volatile("" ::: "memory");
@@ -626,7 +778,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                 // ---------------- R3: dW4~ += dg1^T z (owner: wave w < 4 -> out tile w)
                 launder(cc, qq);
                 // the next pass's (or the next tile's first pass's) eps arrives under this round
-                if (two && p == 0) e = ld_lat(a.eps[1], row0);
+                if (two && p == 0) e = ld_lat(a.eps[1], row0);  // (a 4-line read per wave; the staged copy is gone by now)
                 else if (PREFETCH && tile + (int)gridDim.x < a.ntiles) e = ld_lat(a.eps[0], row0 + (long)gridDim.x * TILE_ROWS);
                 LDS_BARRIER();
                 if (own4) {
@@ -639,6 +791,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
 #pragma unroll
                     for (int kb = 0; kb < TILE_ROWS / 32; ++kb) acc4 = VPC_MFMA_BF(fa4[kb], fb4[kb], acc4);
                 }
+                if (p + 1 == a.npass) asm volatile("" ::"v"(tv));  // the touch loads retire here, long after they were issued
                 if (two) {  // (current, other) <- (other, current)
                     f32x4 t4;
                     t4 = muQ; muQ = muP; muP = t4;
@@ -705,10 +858,15 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
             asm volatile("" ::: "memory");
             int cc = c, qq = q;
             launder(cc, qq);
-            if (!PREFETCH) {
-                request_tile(tile, false);
+            if (staged_in || !PREFETCH) {
                 s0 = *ws_ptr(tile, 0);
                 if (two) s1 = *ws_ptr(tile, 1);
+            }
+            if (staged_in) {
+                f32x4 unused;
+                stage_in(tile, false, unused);
+            } else if (!PREFETCH) {
+                request_tile(tile, false);
             }
             // x and the mask words were requested one tile ahead (request_tile); the packed seeds of both passes come back from
             // the workspace (sweep 1 stored them from this very thread: same address, same lane)
@@ -723,7 +881,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                 {
                     f32x4 mu, lv;
                     make_xb(xr, mw, xb, qq);
-                    enc_fwd(xb, h1b, h2b, mu, lv, cc, qq, ok);
+                    enc_fwd(std::true_type{}, xb, h1b, h2b, mu, lv, cc, qq, ok);
                 }
                 // x, the mask words and the seed registers are dead from here in the last pass (xb is kept for R5): the next
                 // tile's inputs are requested now and arrive under the two staging rounds
@@ -845,8 +1003,8 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
 #ifdef VPC_ABLATE
     STP(13);
     if ((a.dbg & 64) && blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 3 == 0)
-        printf("step blk %d wave %d: prologue %llu E1 %llu g1g2 %llu out %llu R1 %llu dg2 %llu R2 %llu dg1+dz %llu KL+R3 %llu epi1 %llu | E2 %llu dh2+R4 %llu dh1+R5 %llu epi2 %llu\n",
-               blockIdx.x, (int)(threadIdx.x >> 6), T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11], T[12], T[13]);
+        printf("step blk %d wave %d: half0 arrived %llu xwait(rest) %llu | prologue %llu E1 %llu g1g2 %llu out %llu R1 %llu dg2 %llu R2 %llu dg1+dz %llu KL+R3 %llu epi1 %llu | E2 %llu dh2+R4 %llu dh1+R5 %llu epi2 %llu\n",
+               blockIdx.x, (int)(threadIdx.x >> 6), T[15], T[14], T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11], T[12], T[13]);
 #endif
 }
 
@@ -965,12 +1123,13 @@ extern "C" int vpc_step_fused_bf16(const float* x, const float* img_c, int npass
     for (int p = 0; p < npass; ++p)
         if (a.mB[p] && (npass != 2 || a.mB[p] != a.m[1 - p])) return VPC_ERR_ARG;
     a.ntiles = (int)((B + TILE_ROWS - 1) / TILE_ROWS);
+    if (const char* e = getenv("VPC_STEP_STAGGER")) a.stagger = atoi(e);
 #ifdef VPC_ABLATE
     if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
 #endif
     const int grid = a.ntiles < num_cus() ? a.ntiles : num_cus();
     if (nblocks_out) *nblocks_out = grid;
-    auto kern = step_bf16_kernel<8>;
+    auto kern = (d == 128 && !PREFETCH) ? step_bf16_kernel<8, true> : step_bf16_kernel<8, false>;
     if (!lds_attr_done(reinterpret_cast<const void*>(kern), STEP_LDS)) return VPC_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), STEP_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
