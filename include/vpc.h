@@ -180,6 +180,15 @@ int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, long enc_str
                          float bp, float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
                          float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, long step, const int* pack_idx, float* img, void* stream);
+/* the same, re-packing the compact bf16 image of the whole-step kernel instead of the fp32 images: pack_idx_c / img_c of
+ * vpc_step_build_indices_bf16 (a plain-bf16 step then needs no vpc_step_pack_weights_bf16 launch) */
+int vpc_reduce_step_adam_bf16c(const float* enc_partials, int enc_blocks, long enc_stride, const float* dec_partials,
+                         int dec_blocks, long dec_stride, const int* grad_idx, const int* inv_maps, float* grad_out,
+                         int n_enc, int n,
+                         const double* loss_partials, int loss_blocks, float cA0, float cE0, float cA1, float bq,
+                         float bp, float cr, float wml, long B_local, long B_global, int d, float* out9, float* accum,
+                         float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                         float eps, long step, const int* pack_idx_c, float* img_c, void* stream);
 
 /* ---- random draws (Philox4x32-10, counter = GLOBAL element-group index + offset) -------------------
  * Data parallel: a rank that holds rows [row_lo, row_lo + B_local) of a global batch passes

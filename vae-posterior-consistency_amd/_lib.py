@@ -62,6 +62,8 @@ _PROTOS = {
                         P],
     "vpc_reduce_step_adam": [P, I, L_, P, I, L_, P, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, P, P, F, F,
                              F, F, L_, P, P, P],
+    "vpc_reduce_step_adam_bf16c": [P, I, L_, P, I, L_, P, P, P, I, I, P, I, F, F, F, F, F, F, F, L_, L_, I, P, P, P, P, P, F, F,
+                             F, F, L_, P, P, P],
     "vpc_draw_mask": [P, P, L_, F, ULL, ULL, L_, P],
     "vpc_draw_step": [P, P, L_, F, P, L_, ULL, ULL, ULL, P, L_, L_, L_, L_, I, P],
     "vpc_fill_normal": [P, L_, ULL, ULL, P, L_, L_, L_, I, P],

@@ -105,6 +105,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int* __re
 struct AdamFuse {
     float* param; float* m; float* v; const int* pack_idx; float* img;
     float lr, b1, b2, eps, bc1, bc2_sqrt;
+    int bf16c;  // 1: (pack_idx, img) are the compact bf16 image tables of the whole-step kernel (vpc_step_build_indices_bf16)
 };
 __device__ __forceinline__ void adam_apply(const AdamFuse& A, int i, float g) {
 #pragma clang fp contract(off)  // one rounding sequence wherever this is inlined (stand-alone Adam == fused Adam, bitwise)
@@ -115,7 +116,12 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& A, int i, float g) {
     const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
     const float pnew = A.param[i] - (A.lr / A.bc1) * (mi / denom);
     A.param[i] = pnew;
-    if (A.pack_idx) A.img[A.pack_idx[i]] = pnew;
+    if (A.pack_idx) {
+        const int e = A.pack_idx[i];
+        if (!A.bf16c) A.img[e] = pnew;
+        else if (e < 0) A.img[-(e + 1)] = pnew;  // the layer-1 bias stays fp32
+        else reinterpret_cast<unsigned short*>(A.img)[e] = (unsigned short)(pk_bf16(pnew, 0.f) & 0xffffu);
+    }
 }
 __device__ __forceinline__ void reduce_body(const float* __restrict__ part, int nblocks, long stride,
                                             const int* __restrict__ idx, float* __restrict__ out, int n, float scale,
@@ -163,7 +169,7 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
         bc1 = (float)(1.0 - pow((double)b1, t));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
     }
-    adam_apply(AdamFuse{param, m, v, pack_idx, img, lr, b1, b2, eps, bc1, bc2_sqrt}, i, grad[i]);
+    adam_apply(AdamFuse{param, m, v, pack_idx, img, lr, b1, b2, eps, bc1, bc2_sqrt, 0}, i, grad[i]);
 }
 
 // loss_part[nblocks][8] doubles -> out[9] floats; out[0] = train loss (already / B), out[1..8] = raw sums;
@@ -802,7 +808,40 @@ extern "C" int vpc_reduce_step_adam(const float* enc_partials, int enc_blocks, l
                      1.0 / (double)B_global};
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2)};
+    const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), 0};
+    if (inv_usable(inv_maps, enc_partials, enc_stride, dec_partials, dec_stride)) {
+        const int *invE = inv_maps, *invD = inv_maps + enc_stride;
+        const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);
+        hipLaunchKernelGGL(reduce_step_v2_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                           enc_stride, dec_partials, dec_blocks, dec_stride, invE, invD, grad_out, loss_partials,
+                           loss_blocks, k, out9, accum, (long long*)nullptr, 0LL, A);
+        return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+    }
+    const int grid = (n_enc + 31) / 32 + (n - n_enc + 31) / 32 + 1;
+    hipLaunchKernelGGL(reduce_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc_partials, enc_blocks,
+                       enc_stride, dec_partials, dec_blocks, dec_stride, grad_idx, grad_out, n_enc, n, loss_partials,
+                       loss_blocks, k, out9, accum, (long long*)nullptr, 0LL, A);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// The same with the compact bf16 image of the whole-step kernel as the re-pack target (pack_idx_c / img_c of
+// vpc_step_build_indices_bf16): a bf16 step then needs no separate pack launch.
+extern "C" int vpc_reduce_step_adam_bf16c(const float* enc_partials, int enc_blocks, long enc_stride,
+                                    const float* dec_partials, int dec_blocks, long dec_stride, const int* grad_idx,
+                                    const int* inv_maps, float* grad_out, int n_enc, int n,
+                                    const double* loss_partials, int loss_blocks,
+                                    float cA0, float cE0, float cA1, float bq, float bp, float cr, float wml,
+                                    long B_local, long B_global, int d, float* out9, float* accum, float* params,
+                                          float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                    long step, const int* pack_idx, float* img, void* stream) {
+    if (!enc_partials || !dec_partials || !grad_idx || !grad_out || !loss_partials || !out9) return VPC_ERR_ARG;
+    if (enc_blocks <= 0 || dec_blocks <= 0 || loss_blocks <= 0 || n_enc <= 0 || n <= n_enc) return VPC_ERR_ARG;
+    if (!params || !exp_avg || !exp_avg_sq || step < 1 || (pack_idx == nullptr) != (img == nullptr)) return VPC_ERR_ARG;
+    const LossCoef k{cA0, cE0, cA1, bq, bp, cr, wml, 0.91893853320467274178 * (double)B_local * (double)d,
+                     1.0 / (double)B_global};
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const AdamFuse A{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), 1};
     if (inv_usable(inv_maps, enc_partials, enc_stride, dec_partials, dec_stride)) {
         const int *invE = inv_maps, *invD = inv_maps + enc_stride;
         const int grid2 = (int)((enc_stride / 4 + 7) / 8 + (dec_stride / 4 + 7) / 8 + 1);

@@ -367,6 +367,14 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         const __amdgpu_buffer_rsrc_t rm0 = mask_rsrc(a.m[0], r0), rm1 = mask_rsrc(a.m[two ? 1 : 0], r0);
         f32x4 gx[4], gm0, gm1 = zero4(), ge = zero4();
         auto issue = [&](int hc) {
+#ifdef VPC_ABLATE
+            if (a.dbg & 16) {  // timing without the tile loads (wrong results)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gx[k] = zero4();
+                gm0 = zero4();
+                return;
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int gi = (4 * w + k) * 64 + lane;  // row gi >> 4, granule gi & 15 of this column half
@@ -529,31 +537,24 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                         if (4 * q + j == a.L) z[j] = 1.f;  // constant feature that drives the bias chain
                     const Op zb = pack2(z, zero4());
                     Op g2b[4];
-                    uint32_t gm2 = 0;
                     const Op zin[1] = {zb};
                     // g1 = relu(W4~ z): formed here for the forward and AGAIN in front of R2 (4 MFMAs instead of 8 registers held
                     // across the output-tile phase)
-                    auto make_g1 = [&](Op (&g1b)[2], uint32_t& gm1) {
+                    auto make_g1 = [&](Op (&g1b)[2]) {
                         f32x4 hprev = zero4();
-                        gm1 = 0;
                         c_layer_fwd<32, 1, H2T>(W4, zin, cc, qq, [&](int mt, f32x4 acc) {
                             const f32x4 h = relu4(acc);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) gm1 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
                             if (mt & 1) g1b[mt >> 1] = pack2(hprev, h);
                             hprev = h;
                         });
                     };
                     {
                         Op g1b[2];
-                        uint32_t gm1_unused;
-                        make_g1(g1b, gm1_unused);
+                        make_g1(g1b);
                         launder(cc, qq);
                         f32x4 hprev = zero4();
                         c_layer_fwd<64, 2, H1T>(W5, g1b, cc, qq, [&](int mt, f32x4 acc) {
                             const f32x4 h = relu4(acc);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) gm2 |= (h[j] > 0.f ? 1u : 0u) << (4 * mt + j);
                             if (mt & 1) g2b[mt >> 1] = pack2(hprev, h);
                             else if (mt + 1 == H1T) g2b[mt >> 1] = pack2(h, zero4());
                             hprev = h;
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             const f32x4 mA = mask_to_f32(ua);
-                            const f32x4 mE = mA * (1.f - mask_to_f32(ub));  // no second mask: ub aliases ua, mA (1 - mA) = 0
+                            const f32x4 mE = mask_to_f32(ua & ~ub);  // mA (1 - mB) on the 0 / 1 bytes; no second mask: ub aliases ua -> 0
                             f32x4 dp4;
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     launder(cc, qq);
                     // ---------------- dg2 = relu'(g2) * (W6~^T dpre): B operands = the lane's own dpre chunks, back from their
                     // staging slots (own writes: no barrier)
-                    Op dpreb[KB1];
+                    Op dpreb[KB1], g2r[4];  // g2r: the lane's own packed g2 (slots 8-14), the ReLU gates of this dgrad
                     {
                         const int so = bf_stage_off<ST_FT>(16 * w + cc, 0, qq);
 #pragma unroll
@@ -660,12 +661,19 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                             const u32x2 hi2 = (2 * kb + 1 < DT) ? *reinterpret_cast<const u32x2*>(st + so + 128 * kb + 64) : u32x2{0u, 0u};
                             dpreb[kb] = __builtin_bit_cast(Op, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
                         }
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const u32x2 lo2 = *reinterpret_cast<const u32x2*>(st + so + 64 * 8 + 128 * kb);
+                            const u32x2 hi2 = (2 * kb + 1 < H1T) ? *reinterpret_cast<const u32x2*>(st + so + 64 * 8 + 128 * kb + 64) : u32x2{0u, 0u};
+                            g2r[kb] = __builtin_bit_cast(Op, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+                        }
                     }
                     Op dg2b[4];
                     {
                         f32x4 hprev = zero4();
                         c_layer_T<128, KB1, H1T, DT>(W6, dpreb, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                            const f32x4 h = gate_bits(acc, gm2, mt);
+                            const BfOp gp = {g2r[mt >> 1], g2r[mt >> 1]};
+                            const f32x4 h = bf_gate(acc, gp, mt & 1);
                             if (mt & 1) dg2b[mt >> 1] = pack2(hprev, h);
                             else if (mt + 1 == H1T) dg2b[mt >> 1] = pack2(h, zero4());
                             hprev = h;
@@ -675,9 +683,8 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     VPC_CUT();
                     launder(cc, qq);
                     // ---------------- R2: dW5~ += dg2^T g1   (owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3)
-                    Op g1b[2];
-                    uint32_t gm1;
-                    make_g1(g1b, gm1);
+                    Op g1b[2];  // (also the ReLU gate of dg1 below: a packed relu output is non-zero where the unit is active)
+                    make_g1(g1b);
                     LDS_BARRIER();
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 0, kb, qq, dg2b[kb]);
@@ -707,7 +714,8 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     {
                         f32x4 hprev = zero4();
                         c_layer_T<64, 4, H2T, H1T>(W5, dg2b, 16 * qq + cc, [&](int mt, f32x4 acc) {
-                            const f32x4 h = gate_bits(acc, gm1, mt);
+                            const BfOp gp = {g1b[mt >> 1], g1b[mt >> 1]};
+                            const f32x4 h = bf_gate(acc, gp, mt & 1);
                             if (mt & 1) dg1b[mt >> 1] = pack2(hprev, h);
                             hprev = h;
                         });

@@ -203,11 +203,13 @@ class FusedTrainer:
         if row_lo < 0 or row_lo + B > Bg:
             raise ValueError(f"rows [{row_lo}, {row_lo + B}) are not inside the global batch of {Bg}")
         co = self.coefficients(epoch, alpha, beta, beta_annealing)
-        img = m._images()
-        enc_img, dec_img = img[:lay.enc_img], img[lay.enc_img:]
         two = not self.vanilla
         use_step = bool(self.prec) and self._step_ok and ops.step_fused_applicable(B, dk, Ld, 2 if two else 1)
         self._used_step_fused = use_step
+        # the model's fp32 images (what the fp32 kernels read and the Adam launches re-pack); the whole-step bf16 kernel has its
+        # own image and leaves these stale (invalidate_images below), so it must not ask for them every step
+        img = None if use_step else m._images()
+        enc_img, dec_img = (None, None) if use_step else (img[:lay.enc_img], img[lay.enc_img:])
         if self.prec:  # bf16 images, re-packed from the flat parameters after an optimiser step (lazily, see __init__)
             enc_img, dec_img = self.img_bf[:self.enc_img_bf], self.img_bf[self.enc_img_bf:]
             kind = "step" if use_step else "pair"
@@ -273,6 +275,17 @@ class FusedTrainer:
         self.last_blocks = (nbE, nbD)
         if update and not self.dp and _state is None:
             self.step_count += 1
+            if use_step:
+                # the fused Adam re-packs the whole-step kernel's compact bf16 image itself (no pack launch); the model's fp32
+                # images and the pair-slot bf16 image go stale and are re-packed by whoever needs them next
+                self._timed("reduce_step", ops.reduce_step_adam, self.partE, nbE, lay.enc_part, self.partD, nbD,
+                            lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
+                            cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
+                            self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                            self.step_count, self.pidx_c, self.img_c, self.inv, True)
+                m.invalidate_images()
+                self._stale = {"pair": True, "step": False}
+                return
             self._timed("reduce_step", ops.reduce_step_adam, self.partE, nbE, lay.enc_part, self.partD, nbD,
                         lay.dec_part, self.gidx, self.grad, lay.n_enc, self.loss_part, nbD, co["cA"][0], co["cE"][0],
                         cA1, co["bq"], co["bp"], co["cr"], co["wml"], B, Bg, d, self.out9, self.accum, m._flat,
@@ -291,8 +304,10 @@ class FusedTrainer:
         if update:
             self.step_count += 1
             # under data parallelism the Adam launch also adds the all-reduced loss to the epoch accumulator
+            if use_step:
+                m.invalidate_images()
             ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
-                        self.lr, self.betas[0], self.betas[1], self.eps, self.pidx, img,
+                        self.lr, self.betas[0], self.betas[1], self.eps, None if use_step else self.pidx, img,
                         None if _state is None else _state[0:1],
                         loss_in=self.out9 if self.dp else None, accum=self.accum if self.dp else None)
             if self.prec:

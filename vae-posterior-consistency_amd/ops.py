@@ -160,8 +160,10 @@ def reduce_step(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc,
 
 def reduce_step_adam(partE, nbE, strideE, partD, nbD, strideD, grad_idx, grad, n_enc, loss_part, nbL, cA0, cE0, cA1, bq,
                      bp, cr, wml, B_local, B_global, d, out9, accum, params, m, v, lr, beta1, beta2, eps, step, pack_idx,
-                     img, inv_maps=None):
-    check(lib().vpc_reduce_step_adam(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(inv_maps),
+                     img, inv_maps=None, bf16c=False):
+    """bf16c: (pack_idx, img) are the compact bf16 image tables of the whole-step kernel (re-packed instead of the fp32 images)."""
+    fn = lib().vpc_reduce_step_adam_bf16c if bf16c else lib().vpc_reduce_step_adam
+    check(fn(ptr(partE), nbE, strideE, ptr(partD), nbD, strideD, ptr(grad_idx), ptr(inv_maps),
                                      ptr(grad), n_enc, grad.numel(), ptr(loss_part), nbL, cA0, cE0, cA1, bq, bp, cr, wml, B_local,
                                      B_global, d, ptr(out9), ptr(accum), ptr(params), ptr(m), ptr(v), lr, beta1, beta2,
                                      eps, int(step), ptr(pack_idx), ptr(img), stream_ptr()), "vpc_reduce_step_adam")
