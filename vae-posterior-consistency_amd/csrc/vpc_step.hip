@@ -66,6 +66,10 @@ typedef bf16x8 Op;  // one MFMA operand: 8 k-slots per lane
 #define VPC_STEP_PREFETCH 0  // 1: request a tile's inputs one tile ahead (see request_tile); measured, see profiles/r03_notes.md
 #endif
 constexpr bool PREFETCH = VPC_STEP_PREFETCH != 0;
+#ifndef VPC_STEP_AHEAD
+#define VPC_STEP_AHEAD 0  // staged tile inputs: the first column half of a tile is requested one tile ahead (28 registers)
+#endif
+constexpr bool AHEAD = VPC_STEP_AHEAD != 0;
 
 // Workgroup barrier for LDS hand-offs only: the wave's own LDS operations are complete (lgkmcnt(0)), global memory
 // operations stay in flight.  __syncthreads() is a fence as well - hipcc puts s_waitcnt vmcnt(0) in front of s_barrier - and
@@ -361,32 +365,33 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
     constexpr int SX = 0, SM0 = 8192, SM1 = 10240, SE0 = 12288;  // dword offsets inside the staging area
     static_assert(SE0 + 2048 <= ST_DW, "staged tile inputs");
     constexpr bool staged_in = STAGED;  // (instantiated for obs_dim == 128; other widths load straight into C layout)
-    auto stage_in = [&](int tile, bool with_eps, f32x4& ev) {
+    f32x4 gx[4], gm0 = zero4(), gm1 = zero4(), ge = zero4();  // one column half of a tile on its way from global memory
+    auto stage_issue = [&](int tile, int hc, bool with_eps) {
         const long r0 = (long)tile * TILE_ROWS;
         const __amdgpu_buffer_rsrc_t rx = rows_rsrc(a.x, r0, a.B, 128);
         const __amdgpu_buffer_rsrc_t rm0 = mask_rsrc(a.m[0], r0), rm1 = mask_rsrc(a.m[two ? 1 : 0], r0);
-        f32x4 gx[4], gm0, gm1 = zero4(), ge = zero4();
-        auto issue = [&](int hc) {
 #ifdef VPC_ABLATE
-            if (a.dbg & 16) {  // timing without the tile loads (wrong results)
+        if (a.dbg & 16) {  // timing without the tile loads (wrong results)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gx[k] = zero4();
-                gm0 = zero4();
-                return;
-            }
+            for (int k = 0; k < 4; ++k) gx[k] = zero4();
+            gm0 = zero4();
+            return;
+        }
 #endif
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int gi = (4 * w + k) * 64 + lane;  // row gi >> 4, granule gi & 15 of this column half
-                gx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (gi >> 4) * 512 + hc * 256 + (gi & 15) * 16, 0, 0));
-            }
-            const int gi = w * 64 + lane;  // row gi >> 2, granule gi & 3
-            gm0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm0, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
-            if (two) gm1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm1, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
-            if (with_eps && hc == 0)
-                ge = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.eps[0], r0, a.B, 16), gi * 16, 0, 0));
-        };
-        issue(0);
+        for (int k = 0; k < 4; ++k) {
+            const int gi = (4 * w + k) * 64 + lane;  // row gi >> 4, granule gi & 15 of this column half
+            gx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (gi >> 4) * 512 + hc * 256 + (gi & 15) * 16, 0, 0));
+        }
+        const int gi = w * 64 + lane;  // row gi >> 2, granule gi & 3
+        gm0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm0, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
+        if (two) gm1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm1, (gi >> 2) * 128 + hc * 64 + (gi & 3) * 16, 0, 0));
+        if (with_eps && hc == 0)
+            ge = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.eps[0], r0, a.B, 16), gi * 16, 0, 0));
+    };
+    // (the first half is already requested when AHEAD: by the prologue / the previous tile / the end of the other sweep)
+    auto stage_in = [&](int tile, bool with_eps, f32x4& ev) {
+        if (!AHEAD) stage_issue(tile, 0, with_eps);
 #pragma unroll
         for (int hc = 0; hc < 2; ++hc) {
             LDS_BARRIER();  // the staging area is free: every wave is past its reads of the previous round / half
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
 #ifdef VPC_ABLATE
             if (hc == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STP(15); }
 #endif
-            if (hc == 0) issue(1);  // the second half's loads fly while the first half is read
+            if (hc == 0) stage_issue(tile, 1, with_eps);  // the second half's loads fly while the first half is read
             LDS_BARRIER();
             const int lr = 16 * w + c;
 #pragma unroll
@@ -451,6 +456,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
             request_tile(blockIdx.x, false);
             e = ld_lat(a.eps[0], (long)blockIdx.x * TILE_ROWS);
         }
+        if (staged_in && AHEAD && (int)blockIdx.x < a.ntiles) stage_issue(blockIdx.x, 0, true);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = (u * THREADS + (int)threadIdx.x) * 4;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
 #ifdef VPC_ABLATE
             if (!(a.dbg & 8))
 #endif
-            if (!PREFETCH && tile + (int)gridDim.x < a.ntiles) tv = touch(tile + (int)gridDim.x);
+            if (!PREFETCH && !(staged_in && AHEAD) && tile + (int)gridDim.x < a.ntiles) tv = touch(tile + (int)gridDim.x);
             STP(1);
             for (int p = 0; p < a.npass; ++p) {
                 asm volatile("" ::: "memory");
@@ -623,6 +629,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                     launder(cc, qq);
                     // x and the mask words are dead after the last pass's output tiles: the next tile's are requested now
                     if (PREFETCH && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) request_tile(tile + (int)gridDim.x, two);
+                    if (staged_in && AHEAD && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) stage_issue(tile + (int)gridDim.x, 0, true);
                     // ---------------- R1: dW6~ += dpre^T g2   (owner: wave w -> out tile w, all 7 in tiles)
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) st_op<H1T>(st, lrow, 8, kb, qq, g2b[kb]);
@@ -812,6 +819,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
         }
         // sweep 2's first tile is requested before this sweep's partial-block stores
         if (PREFETCH && (int)blockIdx.x < a.ntiles) request_tile(blockIdx.x, false);
+        if (staged_in && AHEAD && (int)blockIdx.x < a.ntiles) stage_issue(blockIdx.x, 0, false);
         // ---------------- decoder partial block, dW3 and the loss terms
         {
             float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
@@ -893,6 +901,7 @@ __global__ __launch_bounds__(THREADS) void step_bf16_kernel(StepArgs a) {
                 }
                 // x, the mask words and the seed registers are dead from here in the last pass (xb is kept for R5): the next
                 // tile's inputs are requested now and arrive under the two staging rounds
+                if (staged_in && AHEAD && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) stage_issue(tile + (int)gridDim.x, 0, false);
                 if (PREFETCH && p + 1 == a.npass && tile + (int)gridDim.x < a.ntiles) {
                     const int nt = tile + (int)gridDim.x;
                     request_tile(nt, two);
