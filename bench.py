@@ -165,7 +165,16 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    return subprocess.call(cmd, env=env)
+    # the ranks' stdout is relayed line by line, JSON lines only: the contract is ONE JSON line on stdout, and some
+    # process-group back ends (gloo) print their own chatter there
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def ranks_seen(vpc, tr, world, dev):

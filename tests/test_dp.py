@@ -94,7 +94,7 @@ def test_shard_rows_partition():
 
 
 # ----------------------------------------------------------------------------------------------- GPU, 2 ranks
-def _gpu_worker(rank, world, port, d, B, steps, out, device_draws=False):
+def _gpu_worker(rank, world, port, d, B, steps, out, device_draws=False, precision="f32"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     vpc.dp.init_from_env(backend="gloo")
@@ -104,7 +104,7 @@ def _gpu_worker(rank, world, port, d, B, steps, out, device_draws=False):
     sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
     m.to(dev)
     vpc.dp.broadcast_parameters(m.flatten_parameters())
-    tr = vpc.FusedTrainer(m, world_size=world, rank=rank)
+    tr = vpc.FusedTrainer(m, world_size=world, rank=rank, precision=precision)
     x, mask, mask_p, eq, ep = _inputs(B, d)
     lo, hi = vpc.dp.shard_rows(B, rank, world)
     losses = []
@@ -146,12 +146,41 @@ def test_two_rank_fused_trainer_matches_single_process():
     assert abs(tr.epoch_total() - total2) <= 1e-5 * abs(total2)
 
 
-def _single_trainer(d, B, dev, seed=0):
+@pytest.mark.gpu
+def test_two_rank_bf16_step_kernel_matches_single_process(monkeypatch):
+    """The whole-step bf16 kernel under data parallelism (throughput workgroup shape forced: VPC_TILE=128): two ranks on shards
+    of 256 rows = the single process on 512 rows up to fp32 reduction order - the operand rounding is per row and identical -
+    incl. the Adam updates (the compact image is re-packed lazily after the all-reduced update)."""
+    monkeypatch.setenv("VPC_TILE", "128")
+    d, B, steps = 128, 512, 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, d, B, steps, out, False, "bf16")) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses2, flat2, total2 = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    tr, m = _single_trainer(d, B, dev, precision="bf16")
+    x, mask, mask_p, eq, ep = _inputs(B, d)
+    for i in range(steps):
+        tr.step(x.to(dev), mask.to(dev), mask_p.to(dev), eq.to(dev), ep.to(dev), alpha=0.8, beta=0.9, epoch=i + 1)
+        assert tr._used_step_fused
+        assert abs(tr.loss_value() - losses2[i]) <= 1e-5 * abs(losses2[i]), (i, tr.loss_value(), losses2[i])
+    flat1 = m._flat.cpu().numpy()
+    assert np.max(np.abs(flat1 - flat2)) <= 1e-4 * np.max(np.abs(flat1))
+    assert abs(tr.epoch_total() - total2) <= 1e-5 * abs(total2)
+
+
+def _single_trainer(d, B, dev, seed=0, precision="f32"):
     params = O.init_params(d, L, seed=5)
     m = vpc.Reg_VAE(d, 500, 10, L, {"batch_size": B, "patience": 1}, "dp", "kl_reg")
     sd = m.state_dict(); sd.update({k: v.clone() for k, v in params.items()}); m.load_state_dict(sd)
     m.to(dev)
-    return vpc.FusedTrainer(m, seed=seed), m
+    return vpc.FusedTrainer(m, seed=seed, precision=precision), m
 
 
 @pytest.mark.gpu

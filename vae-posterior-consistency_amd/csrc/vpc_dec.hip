@@ -379,7 +379,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
-                        __syncthreads();
+                        lds_barrier();
                         if (BF) {
 #pragma unroll
                             for (int t = 0; t < DT; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dpre[ch][t]);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                             for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[ch][t], sb);
                         }
-                        __syncthreads();
+                        lds_barrier();
                         if (VPC_DBG(1)) continue;
                         if (BF) {
 #pragma unroll
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
-                        __syncthreads();
+                        lds_barrier();
                         if (BF) {
 #pragma unroll
                             for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dg2[ch][t]);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                             for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1[ch][t], sb);
                         }
-                        __syncthreads();
+                        lds_barrier();
                         if (VPC_DBG(1)) continue;
                         if (BF) {
 #pragma unroll
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
 #pragma unroll
                     for (int ch = 0; ch < NB; ++ch) {
                         if (VPC_DBG(2)) continue;
-                        __syncthreads();
+                        lds_barrier();
                         if (BF) {
 #pragma unroll
                             for (int t = 0; t < H2T; ++t) bf_stage_write<PREC, FTA>(sAh, sAl, 16 * w + cc, t, qq, dg1[ch][t]);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecArgs a) {
                             for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[ch][t], sb);
                             stage_write_b<CH>(stB, 0, z[ch][0], sb);
                         }
-                        __syncthreads();
+                        lds_barrier();
                         if (BF) {
 #pragma unroll
                             for (int sb2 = 0; sb2 < SKB; ++sb2) {

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 launder(cc, qq);
 #pragma unroll
                 for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     if (BF) {
                         if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                         for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, g2[0][t], sb);
                     }
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     if (BF) {
                         if (own6 && !ABL(4)) {
 #pragma unroll
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 }
 #pragma unroll
                 for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     if (BF) {
                         if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
 #pragma unroll
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stB, t, g1r[0][t], sb);
                     }
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     // owner: wave w -> in tile w & 3 of out tiles 4 (w >> 2) .. + 3; out tile 7 does not exist, so waves 4..7
                     // run three: 7 tiles on every SIMD (waves s and s + 4) instead of 8 / 8 / 8 / 4 with one wave per out tile
                     if (BF) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                 if (BF) bf_acts<PREC, H2T>(dg1[0], dg1b);
 #pragma unroll
                 for (int r = 0; r < (BF ? ROUNDS : 2); ++r) {
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     if (BF) {
                         if ((ROUNDS == 1 || round_w == r) && !ABL(1)) {
 #pragma unroll
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(DEC8_THREADS) void dec8_kernel(DecArgs a) {
                         for (int t = 0; t < H2T; ++t) stage_write_b<CH>(stA, t, dg1[0][t], sb);
                         stage_write_b<CH>(stB, 0, z[0][0], sb);
                     }
-                    if (!ABL(2)) __syncthreads();
+                    if (!ABL(2)) lds_barrier();
                     if (BF) {
                         if (own4 && !ABL(4)) {
 #pragma unroll

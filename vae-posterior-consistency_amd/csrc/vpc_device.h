@@ -337,6 +337,12 @@ __device__ __forceinline__ void launder(int& c, int& q) {
     __builtin_amdgcn_sched_barrier(0);  // phases are scheduled separately: bounds live ranges at 256 VGPRs
 }
 
+// Workgroup barrier for LDS hand-offs only: the wave's own LDS operations are complete (lgkmcnt(0)), global memory operations
+// stay in flight.  __syncthreads() is a fence as well - hipcc puts s_waitcnt vmcnt(0) in front of s_barrier - so every
+// staging round also waited for whatever had been requested from global memory ahead of its use (next tile's x / mask words,
+// pass-end operands, the B fragments read straight from global memory in the encoder backward).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 64-lane sum without LDS traffic: four DPP adds give every lane its 16-lane row sum, four v_readlane + adds the
 // total (uniform).  ~12 VALU instructions against 6 dependent ds_bpermute round trips for the shuffle version.
 template <int CTRL>

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             VPC_STAMP(2);
             // ---- dW2~ += dh2 * h1^T   (owner: wave w -> in tiles w + NW o < 7, all 4 out tiles)
             launder(cc, qq);
-            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(2)) lds_barrier();
             if (BF && !ABLE(1)) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) bf_stage_write_op<PREC, 7, H2T>(sAh, sAl, 16 * w + cc, kb, qq, dh2b[kb]);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) stage_write_b<CH>(stB, t, h1[t], sb);
             }
-            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(2)) lds_barrier();
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
                 if (PREC != PREC_F32) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
             VPC_STAMP(4);
             // ---- dW1 += dh1 * (x*mask)^T   (owner: wave w -> in tiles w + NW o < DT, all 7 out tiles; B straight from global)
             launder(cc, qq);
-            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(2)) lds_barrier();
             if (BF && !ABLE(1)) {
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) bf_stage_write<PREC, 7>(sAh, sAl, 16 * w + cc, t, qq, dh1[t]);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void enc_bwd_kernel(EncBw
                 stage_write_b<CH>(stB, H2T, dml[0], sb);
                 stage_write_b<CH>(stB, H2T + 1, dml[1], sb);
             }
-            if (!ABLE(2)) __syncthreads();
+            if (!ABLE(2)) lds_barrier();
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
                 const int t8 = w + NW * o;

@@ -71,10 +71,7 @@ constexpr bool PREFETCH = VPC_STEP_PREFETCH != 0;
 #endif
 constexpr bool AHEAD = VPC_STEP_AHEAD != 0;
 
-// Workgroup barrier for LDS hand-offs only: the wave's own LDS operations are complete (lgkmcnt(0)), global memory
-// operations stay in flight.  __syncthreads() is a fence as well - hipcc puts s_waitcnt vmcnt(0) in front of s_barrier - and
-// that made every staging round wait for the tile inputs requested one tile ahead (R1 29 k -> 51 k cycles).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (lds_barrier(), vpc_device.h: s_waitcnt lgkmcnt(0); s_barrier - no vmcnt(0) as __syncthreads() carries)
 
 __device__ __forceinline__ Op pack2(f32x4 t0, f32x4 t1) {
     const u32x4 h = {pk_bf16(t0[0], t0[1]), pk_bf16(t0[2], t0[3]), pk_bf16(t1[0], t1[1]), pk_bf16(t1[2], t1[3])};
