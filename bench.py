@@ -311,6 +311,28 @@ def extra_configs(vpc, dev):
     out = []
     TP = {"batch_size": 64, "patience": 100}
     N, d, Ld = 13910, 128, 10
+    # the headline shape in the precision BASELINE configs 2 / 3 name (plain bf16 inputs, fp32 accumulation and loss math):
+    # ONE whole-step kernel (csrc/vpc_step.hip) + draws + gradient reduction / Adam
+    try:
+        Bh = 65536
+        gh = torch.Generator().manual_seed(7)
+        xh = torch.rand(Bh, d, generator=gh).to(dev)
+        mh = (torch.rand(Bh, d, generator=gh) < 0.7).to(dev)
+        torch.manual_seed(0)
+        model = vpc.Reg_VAE(d, 500, 10, Ld, {"batch_size": Bh, "patience": 100}, "bench", "kl_reg").to(dev)
+        tr = vpc.FusedTrainer(model, precision="bf16")
+        dt = timed_steps(lambda: tr.step(xh, mh, alpha=1.0, p_missingness=30), 60, 100)
+        fh = flops_per_sample(d, Ld)["total"]
+        tb = measured_step_traffic(Bh, d, Ld, "bf16", tr.dominant_launch())
+        out.append(dict(config="headline shape, bf16", workload="Reg_VAE kl_reg step, B=65536 d=128, plain bf16 MFMA inputs (whole-step kernel)",
+                        dtype="bf16", ms_per_step=dt * 1e3, samples_per_s=Bh / dt,
+                        roofline=dict(bound="mfma", achieved=fh * Bh / dt / 1e12, peak=PEAK["bf16"], unit="TFLOP/s",
+                                      frac=fh * Bh / dt / 1e12 / PEAK["bf16"], note="whole step incl. draws and Adam"),
+                        step_hbm=None if tb is None else dict(bytes_per_step=tb, achieved_TBps=tb / dt / 1e12,
+                                                              frac=tb / dt / 1e12 / HBM_PEAK_TBS)))
+        del tr, model, xh, mh
+    except Exception as e:
+        out.append(dict(config="headline shape, bf16", error=repr(e)[:200]))
     g = torch.Generator().manual_seed(1)
     x = torch.rand(N, d, generator=g).to(dev)
     m = (torch.rand(N, d, generator=g) < 0.7).to(dev)
