@@ -363,6 +363,20 @@ int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uin
                         float* partE, float* partD, double* loss_partials, float* workspace, int* nblocks_out, long B,
                         int d, int L, void* stream);
 
+/* ---- small-batch whole-step kernel, fp32 (csrc/vpc_small.hip): the same step as vpc_encoder_fwd -> vpc_decoder_fused ->
+ * vpc_encoder_bwd with precision 0 (src/experiment_main/train.py:87-115; src/models/VAE.py:496-507, 403-467) as ONE launch in
+ * which a workgroup owns a 16-row tile and the feature tiles of every layer are split over its 8 waves - for the reference's
+ * own batch sizes (64 / 128, Data/imputation_args*.json) and the per-GPU shards of strong scaling, where the row-tiled kernels
+ * are three serial single-tile latencies.  Weights are read from the fp32 images of vpc_build_indices / vpc_pack_weights in
+ * global memory; partial blocks and loss terms in the layouts of vpc_encoder_bwd / vpc_decoder_fused.  Plain (not
+ * mask-augmented) encoder, obs_dim % 4 == 0; maskB[p] must be NULL or mask[1 - p].
+ * vpc_step_small_max_rows: batches up to this many rows take this path inside FusedTrainer (0 = off; env VPC_STEP_SMALL). */
+long vpc_step_small_max_rows(void);
+int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_img, int npass, const uint8_t* const* mask,
+                       const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
+                       const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar, float* partE,
+                       float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,13 +17,16 @@ TP = {"batch_size": 64, "patience": 100}
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=["auto", "tile128"])
+@pytest.fixture(autouse=True, params=["auto", "tile64", "tile128"])
 def tile_shape(request, monkeypatch):
-    """Every test of this module runs twice: with the library's own choice of workgroup shape (for these batch sizes
-    the small-batch shape: 64-row tiles, 4 waves, passes spread over blockIdx.y) and with the throughput shape forced
-    (VPC_TILE=128: 128-row tiles, 8 waves, passes looped) - csrc/vpc_abi_internal.h `tile_shape`."""
+    """Every test of this module runs three times: with the library's own choice (for these batch sizes the fused fp32 step
+    runs the 16-row N-split kernel csrc/vpc_small.hip; the API path the 64-row small-batch shape), with the 64-row small-batch
+    shape forced (VPC_TILE=64: 4 waves, passes spread over blockIdx.y) and with the throughput shape forced (VPC_TILE=128:
+    128-row tiles, 8 waves, passes looped) - csrc/vpc_abi_internal.h `tile_shape`, csrc/vpc_small.hip."""
     if request.param == "tile128":
         monkeypatch.setenv("VPC_TILE", "128")
+    elif request.param == "tile64":
+        monkeypatch.setenv("VPC_TILE", "64")
     else:
         monkeypatch.delenv("VPC_TILE", raising=False)
     return request.param
@@ -347,7 +350,7 @@ def test_workgroup_shapes_agree(d, B, kind, monkeypatch):
     params = O.init_params(d, L, seed=3)
     x, mask, mask_p, eq, ep = synth(B, d, seed=B)
     res = {}
-    for tile in ("64", "128", "64"):
+    for tile in ("64", "128", "64", "16", "16"):
         monkeypatch.setenv("VPC_TILE", tile)
         m = make_model(vpc.Reg_VAE if kind == "reg" else vpc.vanilla_VAE, d, params)
         tr = vpc.FusedTrainer(m)
@@ -364,6 +367,9 @@ def test_workgroup_shapes_agree(d, B, kind, monkeypatch):
     assert abs(res["64"][0] - res["128"][0]) <= 2e-6 * abs(res["128"][0])
     g64, g128 = res["64"][1].cpu().numpy(), res["128"][1].cpu().numpy()
     assert rel(g64, g128) < 2e-5
+    # the 16-row N-split kernel (csrc/vpc_small.hip): one launch for the whole step, the same partial-block layout
+    assert abs(res["16"][0] - res["128"][0]) <= 2e-6 * abs(res["128"][0])
+    assert rel(res["16"][1].cpu().numpy(), g128) < 2e-5
 
 
 @pytest.mark.parametrize("d,B", [(128, 300), (100, 130), (125, 70), (128, 40000), (128, 65536)])

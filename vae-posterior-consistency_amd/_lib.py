@@ -42,6 +42,8 @@ _PROTOS = {
     "vpc_layout_sizes_bf16": [I, I, I, IP, IP],
     "vpc_build_indices_bf16": [I, I, I, P, P],
     "vpc_pack_weights_bf16": [P, P, P, I, P],
+    "vpc_step_small_max_rows": [],
+    "vpc_step_small_f32": [P, P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, P, F, F, F, F, F, F, P, P, P, IP, L_, I, I, P],
     "vpc_step_fused_applicable": [L_, I, I, I],
     "vpc_step_layout_bf16": [I, I, IP, IP],
     "vpc_step_build_indices_bf16": [I, I, P, P],
@@ -93,7 +95,7 @@ _PROTOS = {
     "vpc_eddi_front_scratch": [L_, I, I],
     "vpc_eddi_front_bwd": [P, P, P, P, P, P, P, P, P, L_, P, P, P, P, I, L_, I, I, P],
 }
-_RESTYPE_LONG = {"vpc_step_workspace_floats", "vpc_linear_wgrad_scratch", "vpc_nm_loss_scratch", "vpc_eddi_front_scratch"}
+_RESTYPE_LONG = {"vpc_step_small_max_rows", "vpc_step_workspace_floats", "vpc_linear_wgrad_scratch", "vpc_nm_loss_scratch", "vpc_eddi_front_scratch"}
 
 _lib = None
 

@@ -1,0 +1,446 @@
+// Small-batch whole-step kernel, fp32 (gfx950): one workgroup of 8 waves per 16-ROW tile, the FEATURE tiles of every layer
+// split over the waves ("N-split"), activations handed from layer to layer through LDS.
+//
+// Reference semantics: the Reg_VAE / vanilla_VAE training step of src/experiment_main/train.py:87-115 (src/models/VAE.py:496-507
+// forward, :403-467 loss, autograd backward) - the same mathematics, fp32 v_mfma_f32_16x16x4_f32 products, weight images, loss
+// coefficients and gradient partial-block layouts as vpc_encoder_fwd -> vpc_decoder_fused -> vpc_encoder_bwd with precision 0.
+//
+// Why.  The row-tiled kernels give a wave 16 batch rows and the whole MLP: a wave's life is the serial chain of all layers
+// (~2 000 dependent MFMAs, 13 + 29 + 17 us for the three kernels at batch 64 - the reference's own batch size,
+// Data/imputation_args.json - whatever the batch, with 8 of the chip's 1 024 SIMDs busy).  Here the 7 / 4 / 2 / 4 / 7 / 8 output
+// tiles of a layer belong to different waves, so a layer is ~30 MFMAs deep instead of ~220 and the step is ONE launch; the price
+// is a workgroup barrier per layer and that the weights are not LDS-resident: every wave reads the A fragments of its tile
+// straight from the fp32 image in global memory (L2-resident, 193 KB; the row-tiled kernels' own image format, so Adam's
+// re-pack serves both), requested one layer ahead.
+// LDS: activations and their gradients of the tile as [16 rows][144] fp32 (features contiguous: the C-layout store of a tile
+// is one ds_write_b128 per lane, the B operand of the next layer one ds_read_b128 per k-tile; the pitch of 144 dwords puts
+// the four 4-row groups of a wgrad's dword reads on different banks).  wgrad contracts over the tile's 16 rows: four MFMAs
+// per 16 x 16 gradient tile, operands read as dwords down the columns.
+// Gradient accumulators live in registers across the tiles of a workgroup in the 8-wave slot layout of vpc_layout.h (the
+// partial blocks are what vpc_reduce_step(_adam) expects).
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "vpc_dec_args.h"
+
+namespace vpc {
+
+constexpr int SP = 144;             // row pitch of the LDS activation buffers (dwords)
+constexpr int SBUF = 16 * SP;       // one buffer: 16 rows
+enum { B_XQ = 0, B_XP, B_H1Q, B_H1P, B_H2Q, B_H2P, B_ML, B_Z, B_G1, B_G2, B_DP, B_DG2, B_DG1, B_DML, B_DH2, B_DH1, B_COUNT };
+constexpr int SMALL_LDS = (B_COUNT * SBUF + WAVES * LOSS_TERMS) * 4;
+static_assert(SMALL_LDS <= 163840, "LDS budget");
+
+struct SmallArgs {
+    const float* x;
+    const float* enc_img;
+    const float* dec_img;
+    const uint8_t* m[2];
+    const uint8_t* mB[2];
+    float cA[2], cE[2];
+    const float* eps[2];
+    const float* eps_ml;
+    float* partE;
+    float* partD;
+    double* loss_part;
+    float bq, bp, cr, wml, inv_B, x_logvar;
+    long B;
+    int d, L, npass, ntiles;
+};
+
+// C-layout tile <-> [row][feature] buffer
+__device__ __forceinline__ f32x4 ld_act(const float* buf, int t, int c, int q) {
+    return *reinterpret_cast<const f32x4*>(buf + c * SP + 16 * t + 4 * q);
+}
+__device__ __forceinline__ void st_act(float* buf, int t, int c, int q, f32x4 v) {
+    *reinterpret_cast<f32x4*>(buf + c * SP + 16 * t + 4 * q) = v;
+}
+// gradient tile (out tile of A-buffer `da`, in tile of B-buffer `xb`) over the 16 rows: acc[m][n] += sum_row da[row][16 ta + m] * xb[row][16 tb + n]
+__device__ __forceinline__ f32x4 wgrad16(const float* da, int ta, const float* xb, int tb, f32x4 acc, int m, int kq) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = VPC_MFMA(da[(4 * s + kq) * SP + 16 * ta + m], xb[(4 * s + kq) * SP + 16 * tb + m], acc);
+    return acc;
+}
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    auto buf = [&](int b) { return lds + b * SBUF; };
+    float* red = lds + B_COUNT * SBUF;
+    constexpr int S1 = s_for_tiles(DT);
+    const EncImg ei(DT);
+    const DecImg di(DT);
+    // (re-derived from opaque base pointers in every tile / pass: the weights never change during the launch, and hipcc
+    // otherwise hoists the global fragment loads of ALL layers out of the loops - 900 bytes of scratch per lane)
+    const float *W1, *b1, *W2, *W3, *W4, *W5, *W6;
+    auto weights = [&]() {
+        const float* e_ = a.enc_img;
+        const float* d_ = a.dec_img;
+        asm volatile("" : "+s"(e_), "+s"(d_)::"memory");
+        W1 = e_ + ei.oW1; b1 = e_ + ei.ob1; W2 = e_ + ei.oW2; W3 = e_ + ei.oW3;
+        W4 = d_ + di.oW4; W5 = d_ + di.oW5; W6 = d_ + di.oW6;
+    };
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const bool two = a.npass == 2;
+    const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
+    constexpr float HL2PI = 0.91893853320467274f;
+
+    // gradient accumulators, 8-wave slot layout (vpc_layout.h)
+    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4(), acc6[H1T], acc5[H2T], acc4 = zero4(), dbacc = zero4();
+#pragma unroll
+    for (int t = 0; t < H1T; ++t) { acc1[t] = zero4(); acc6[t] = zero4(); }
+#pragma unroll
+    for (int t = 0; t < H2T; ++t) { acc2[t] = zero4(); acc5[t] = zero4(); }
+    float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * 16;
+        const bool ok = row0 + c < a.B;
+        // ---- this wave's column tile of x and of the mask words of both passes (range-checked: rows past B read 0; the last
+        // tile's columns past d read column 0 and have their mask words cleared)
+        const bool colok = 16 * w + 4 * q + 3 < a.d;
+        f32x4 xv = zero4();
+        uint32_t mwq = 0, mwp = 0;
+        if (w < DT) {
+            const int vo = c * a.d + (colok ? 16 * w + 4 * q : 0);
+            xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.x, row0, a.B, a.d), 4 * vo, 0, 0));
+            const long rem = (a.B - row0) * (long)a.d;
+            const uint32_t rec = rem > 0xffffffffL ? 0xffffffffu : (uint32_t)rem;
+            mwq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.m[0]) + row0 * a.d, 0, rec, 0x00020000), vo, 0, 0);
+            if (two)
+                mwp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.m[1]) + row0 * a.d, 0, rec, 0x00020000), vo, 0, 0);
+            if (!colok) { mwq = 0; mwp = 0; }
+        }
+        auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
+            return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), c, 16, 4 * q);
+        };
+        __syncthreads();  // the previous tile's last reads of the buffers are done
+        int cc = c, qq = q;
+        launder(cc, qq);
+        // ================================================================ E: encoder forward of both passes
+        for (int p = 0; p < a.npass; ++p) {
+            weights();
+            float* X = buf(p == 0 ? B_XQ : B_XP);
+            float* H1b = buf(p == 0 ? B_H1Q : B_H1P);
+            float* H2b = buf(p == 0 ? B_H2Q : B_H2P);
+            if (w < DT) st_act(X, w, cc, qq, xv * mask_to_f32(p == 0 ? mwq : mwp));  // x.float() * mask  (VAE.py:388)
+            __syncthreads();
+            launder(cc, qq);
+            if (w < H1T) {
+                f32x4 in[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) in[t] = ld_act(X, t, cc, qq);
+                const f32x4 acc = tile_fwd<DT, S1>(W1, w, in, *reinterpret_cast<const f32x4*>(b1 + 16 * w + 4 * qq), cc, qq);
+                st_act(H1b, w, cc, qq, relu4(acc));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            if (w < H2T) {
+                f32x4 in[H1T];
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) in[t] = ld_act(H1b, t, cc, qq);
+                st_act(H2b, w, cc, qq, relu4(tile_fwd<H1T, 128, NK1>(W2, w, in, zero4(), cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            if (w < 2) {  // wave 0: mean tile, wave 1: logvar tile -> ML[row][32 p + 16 w ..]
+                f32x4 in[H2T];
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) in[t] = ld_act(H2b, t, cc, qq);
+                f32x4 o = tile_fwd<H2T, 64, NK2>(W3, w, in, zero4(), cc, qq);
+                if (!ok) o = zero4();  // rows past B: statistics 0
+                st_act(buf(B_ML), 2 * p + w, cc, qq, o);
+            }
+        }
+        __syncthreads();
+            launder(cc, qq);
+        // ================================================================ per pass: decoder, loss, all backward
+        for (int p = 0; p < a.npass; ++p) {
+            weights();
+            const float* X = buf(p == 0 ? B_XQ : B_XP);
+            const float* H1b = buf(p == 0 ? B_H1Q : B_H1P);
+            const float* H2b = buf(p == 0 ? B_H2Q : B_H2P);
+            const f32x4 mu = ld_act(buf(B_ML), 2 * p, cc, qq), lv = ld_act(buf(B_ML), 2 * p + 1, cc, qq);
+            const f32x4 e = ld_lat(a.eps[p]);
+            if (w == 0) {  // z = mean + eps * exp(logvar / 2); z[L] = 1 drives the bias chain
+                f32x4 z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    z[j] = mu[j] + ((4 * qq + j < a.L) ? e[j] : 0.f) * __expf(0.5f * lv[j]);
+                    if (4 * qq + j == a.L) z[j] = 1.f;
+                }
+                st_act(buf(B_Z), 0, cc, qq, z);
+            }
+            __syncthreads();
+            launder(cc, qq);
+            if (w < H2T) {
+                const f32x4 in[1] = {ld_act(buf(B_Z), 0, cc, qq)};
+                st_act(buf(B_G1), w, cc, qq, relu4(tile_fwd<1, S4>(W4, w, in, zero4(), cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            if (w < H1T) {
+                f32x4 in[H2T];
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_G1), t, cc, qq);
+                st_act(buf(B_G2), w, cc, qq, relu4(tile_fwd<H2T, 64, NK2>(W5, w, in, zero4(), cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            if (w < DT) {  // output tile w: forward, loss terms, d / d pre-activation
+                f32x4 in[H1T];
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) in[t] = ld_act(buf(B_G2), t, cc, qq);
+                const f32x4 pre = tile_fwd<H1T, 128, NK1>(W6, w, in, zero4(), cc, qq);
+                const uint32_t ua = p == 0 ? mwq : mwp;
+                const uint32_t ub = a.mB[p] ? (p == 0 ? mwp : mwq) : ua;  // (host: the second mask is the other pass's)
+                const f32x4 mA = mask_to_f32(ua), mE = mask_to_f32(ua & ~ub);
+                const float kA = a.cA[p] * inv_s2 * a.inv_B, kE = a.cE[p] * inv_s2 * a.inv_B, hinv_s2 = 0.5f * inv_s2;
+                f32x4 dp;
+                float sa = 0.f, se = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = fast_sigmoid(pre[j]);
+                    const float diff = xh - xv[j];
+                    const float t = diff * diff * hinv_s2 + half_lv;
+                    sa += mA[j] * t;
+                    se += mE[j] * t;
+                    dp[j] = (kA * mA[j] + kE * mE[j]) * diff * (xh - xh * xh);
+                }
+                if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
+                st_act(buf(B_DP), w, cc, qq, dp);
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW6~ (wave w: out tile w, 7 in tiles)  |  dg2 = relu'(g2) * (W6~^T dpre) (waves 0-6: tile w)
+            if (w < DT) {
+#pragma unroll
+                for (int nt = 0; nt < H1T; ++nt) acc6[nt] = wgrad16(buf(B_DP), w, buf(B_G2), nt, acc6[nt], cc, qq);
+            }
+            if (w < H1T) {
+                f32x4 in[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) in[t] = ld_act(buf(B_DP), t, cc, qq);
+                st_act(buf(B_DG2), w, cc, qq, gate4(tile_T<DT, 128>(W6, w, in, zero4(), cc, qq), ld_act(buf(B_G2), w, cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW5~ (wave w: in tile w & 3 of out tiles 4 (w >> 2) .. + 3)  |  dg1 (waves 0-3)
+            {
+                const int nt5 = w & 3, mt5 = 4 * (w >> 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < 3 || w < 4) acc5[i] = wgrad16(buf(B_DG2), mt5 + i, buf(B_G1), nt5, acc5[i], cc, qq);
+            }
+            if (w < H2T) {
+                f32x4 in[H1T];
+#pragma unroll
+                for (int t = 0; t < H1T; ++t) in[t] = ld_act(buf(B_DG2), t, cc, qq);
+                st_act(buf(B_DG1), w, cc, qq, gate4(tile_T<H1T, 64, NK1>(W5, w, in, zero4(), cc, qq), ld_act(buf(B_G1), w, cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW4~ (waves 0-3: out tile w)  |  wave 4: dz, KL terms, seeds on (mean | logvar) -> DML
+            if (w < H2T) acc4 = wgrad16(buf(B_DG1), w, buf(B_Z), 0, acc4, cc, qq);
+            if (w == 4) {
+                f32x4 in[H2T];
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_DG1), t, cc, qq);
+                const f32x4 dz = tile_T<H2T, S4, NK2>(W4, 0, in, zero4(), cc, qq);
+                const f32x4 mo = two ? ld_act(buf(B_ML), 2 * (1 - p), cc, qq) : zero4();
+                const f32x4 lo = two ? ld_act(buf(B_ML), 2 * (1 - p) + 1, cc, qq) : zero4();
+                f32x4 dmu, dlv;
+                const float b0 = (p == 0) ? a.bq : a.bp;
+                const float sgn = (p == 0) ? 1.f : -1.f;
+                const float crr = two ? a.cr : 0.f;
+                float kl0 = 0.f, klr = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float elv = __expf(lv[j]);
+                    kl0 += 0.5f * (elv + mu[j] * mu[j] - 1.f - lv[j]);
+                    const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                    const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                    const float diff = mq - mp, eip = __expf(-lp), r = __expf(lq - lp);
+                    klr += 0.5f * (r + diff * diff * eip - 1.f - (lq - lp));
+                    const float dm = b0 * mu[j] + sgn * crr * diff * eip;
+                    const float dl = b0 * 0.5f * (elv - 1.f) + crr * 0.5f * ((p == 0) ? (r - 1.f) : (1.f - r - diff * diff * eip));
+                    dmu[j] = dm * a.inv_B;
+                    dlv[j] = dl * a.inv_B;
+                }
+                if (p == 0) { S_kl0q += kl0; if (two) S_klr += klr; } else { S_kl0p += kl0; }
+                if (two && a.wml != 0.f) {  // ml_reg: extra rsample z' of q scored under p (VAE.py:435-440)
+                    const f32x4 e3 = ld_lat(a.eps_ml);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = ok && 4 * qq + j < a.L;
+                        const float e3j = (4 * qq + j < a.L) ? e3[j] : 0.f;
+                        const float mq = (p == 0) ? mu[j] : mo[j], lq = (p == 0) ? lv[j] : lo[j];
+                        const float mp = (p == 0) ? mo[j] : mu[j], lp = (p == 0) ? lo[j] : lv[j];
+                        const float sq = __expf(0.5f * lq), eip = __expf(-lp);
+                        const float dlt = mq + e3j * sq - mp;
+                        const float g = a.wml * dlt * eip * a.inv_B;
+                        if (p == 0) {
+                            if (live) S_zll += -HL2PI - 0.5f * lp - 0.5f * dlt * dlt * eip;
+                            dmu[j] += g;
+                            dlv[j] += g * e3j * 0.5f * sq;
+                        } else {
+                            dmu[j] -= g;
+                            dlv[j] += live ? a.wml * (0.5f - 0.5f * dlt * dlt * eip) * a.inv_B : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ef = (4 * qq + j < a.L) ? e[j] * 0.5f * __expf(0.5f * lv[j]) : 0.f;
+                    dmu[j] = (4 * qq + j < a.L) ? dmu[j] + dz[j] : 0.f;  // columns >= L carry no gradient (dz's column L is db4)
+                    dlv[j] = (4 * qq + j < a.L) ? dlv[j] + dz[j] * ef : 0.f;
+                }
+                st_act(buf(B_DML), 0, cc, qq, dmu);
+                st_act(buf(B_DML), 1, cc, qq, dlv);
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW3~ (wave w: out tile w >> 2, in tile w & 3)  |  dh2 (waves 0-3)
+            acc3 = wgrad16(buf(B_DML), w >> 2, H2b, w & 3, acc3, cc, qq);
+            if (w < H2T) {
+                const f32x4 in[2] = {ld_act(buf(B_DML), 0, cc, qq), ld_act(buf(B_DML), 1, cc, qq)};
+                st_act(buf(B_DH2), w, cc, qq, gate4(tile_T<2, 64>(W3, w, in, zero4(), cc, qq), ld_act(H2b, w, cc, qq)));
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW2~ (waves 0-6: in tile w, 4 out tiles)  |  dh1 (waves 0-6), db1 += column sums of dh1
+            if (w < H1T) {
+#pragma unroll
+                for (int mt = 0; mt < H2T; ++mt) acc2[mt] = wgrad16(buf(B_DH2), mt, H1b, w, acc2[mt], cc, qq);
+                f32x4 in[H2T];
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_DH2), t, cc, qq);
+                const f32x4 dh1 = gate4(tile_T<H2T, 128, NK2>(W2, w, in, zero4(), cc, qq), ld_act(H1b, w, cc, qq));
+                st_act(buf(B_DH1), w, cc, qq, dh1);
+                dbacc += dh1;  // per-lane (row c) running sums; the sum over the rows happens once, at the end
+            }
+            __syncthreads();
+            launder(cc, qq);
+            // ---- dW1 (wave w < DT: in tile w, 7 out tiles)
+            if (w < DT) {
+#pragma unroll
+                for (int mt = 0; mt < H1T; ++mt) acc1[mt] = wgrad16(buf(B_DH1), mt, X, w, acc1[mt], cc, qq);
+            }
+            __syncthreads();
+            launder(cc, qq);
+        }
+    }
+    // ================================================================ partial blocks (vpc_layout.h) and loss terms
+    {
+        float* part = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < H1T; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = (w < DT) ? acc1[mt][j] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = (w < H1T) ? acc2[mt][j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
+        // db1[16 w + 4 q + j] = sum over the 16 rows (lanes c) of dbacc: DPP butterfly inside each 16-lane row
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = dbacc[j];
+            v += dpp_mov<0xB1>(v);
+            v += dpp_mov<0x4E>(v);
+            v += dpp_mov<0x141>(v);
+            v += dpp_mov<0x140>(v);
+            if (c == 0 && w < H1T) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 16 * w + 4 * q + j] = v;
+        }
+        if (w == 7 && lane < 16) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 112 + lane] = 0.f;
+    }
+    {
+        float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
+        const int hi = w >> 2;
+#pragma unroll
+        for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = (w < DT) ? acc6[nt][j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
+        }
+        if (w < H2T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
+        }
+    }
+    const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
+#pragma unroll
+    for (int i = 0; i < LOSS_TERMS; ++i) {
+        const float v = wave_sum_dpp(s[i]);
+        if (lane == 0) red[w * LOSS_TERMS + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_TERMS) {
+        double t = 0.0;
+        for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+    }
+}
+
+}  // namespace vpc
+
+using namespace vpc;
+
+// Rows up to which the library runs an fp32 step through vpc_step_small_f32 (0 = never): by default batches of up to 4
+// sixteen-row tiles per workgroup in one round of CUs.  VPC_TILE=16 forces this path for every batch, VPC_TILE=64 / 128 (the
+// row-tiled workgroup shapes) switch it off, VPC_STEP_SMALL=n sets the row limit (A/B runs, tests).
+extern "C" long vpc_step_small_max_rows(void) {
+    long lim = 64L * num_cus();
+    if (const char* e = getenv("VPC_TILE")) {
+        const int v = atoi(e);
+        if (v == 16) lim = 1L << 40;
+        if (v == 64 || v == 128) lim = 0;
+    }
+    if (const char* e = getenv("VPC_STEP_SMALL")) lim = atol(e);
+    return lim;
+}
+
+extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_img, int npass,
+                                  const uint8_t* const* mask, const uint8_t* const* maskB, const float* cA, const float* cE,
+                                  const float* const* eps, const float* eps_ml, float bq, float bp, float cr, float wml,
+                                  float inv_B, float x_logvar, float* partE, float* partD, double* loss_partials,
+                                  int* nblocks_out, long B, int d, int L, void* stream) {
+    if (!x || !enc_img || !dec_img || !mask || !cA || !cE || !eps || !partE || !partD || !loss_partials) return VPC_ERR_ARG;
+    if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
+    if (d < 4 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(enc_img) || !aligned16(dec_img)) return VPC_ERR_ARG;
+    if (wml != 0.f && !eps_ml) return VPC_ERR_ARG;
+    SmallArgs a{};
+    a.x = x; a.enc_img = enc_img; a.dec_img = dec_img; a.eps_ml = eps_ml; a.partE = partE; a.partD = partD;
+    a.loss_part = loss_partials;
+    a.bq = bq; a.bp = bp; a.cr = cr; a.wml = wml; a.inv_B = inv_B; a.x_logvar = x_logvar;
+    a.B = B; a.d = d; a.L = L; a.npass = npass;
+    for (int p = 0; p < npass; ++p) {
+        if (!mask[p] || !eps[p]) return VPC_ERR_ARG;
+        a.m[p] = mask[p]; a.mB[p] = maskB ? maskB[p] : nullptr; a.cA[p] = cA[p]; a.cE[p] = cE[p]; a.eps[p] = eps[p];
+        if ((uintptr_t)a.m[p] % 4 || !aligned16(a.eps[p])) return VPC_ERR_ARG;
+    }
+    for (int p = 0; p < npass; ++p)  // the second loss mask of a pass must be the other pass's mask (as vpc_step_fused_bf16)
+        if (a.mB[p] && (npass != 2 || a.mB[p] != a.m[1 - p])) return VPC_ERR_ARG;
+    a.ntiles = (int)((B + 15) / 16);
+    const int ncu = num_cus();
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    if (nblocks_out) *nblocks_out = grid;
+    hipStream_t s = (hipStream_t)stream;
+#define VPC_CASE(T)                                                                                        \
+    case T: {                                                                                              \
+        auto kern = step_small_kernel<T>;                                                                  \
+        if (!lds_attr_done(reinterpret_cast<const void*>(kern), SMALL_LDS)) return VPC_ERR_HIP;            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), SMALL_LDS, s, a);                              \
+        return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;                                     \
+    }
+    switch (dt_for(d)) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
+#undef VPC_CASE
+    return VPC_ERR_SHAPE;
+}

@@ -155,6 +155,8 @@ class FusedTrainer:
 
     def dominant_launch(self):
         """Name (as in `timers`) of the launch that carries most of the step's FLOPs in the shape last stepped."""
+        if getattr(self, "_used_step_small", False):
+            return "step_small"
         return "step_fused" if getattr(self, "_used_step_fused", False) else "decoder_fused"
 
     def coefficients(self, epoch, alpha, beta, beta_annealing):
@@ -256,7 +258,14 @@ class FusedTrainer:
         masks = [mask, mask_p] if two else [mask]
         epss = [eq, ep] if two else [eq]
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
-        if use_step:
+        use_small = (not self.prec) and not lay.mask_augm and B <= ops.step_small_max_rows()
+        self._used_step_small = use_small
+        if use_small:
+            # ---- fp32, small batch: the whole step in ONE launch, 16-row tiles with the feature tiles split over the waves
+            nbE = nbD = self._timed("step_small", ops.step_small_f32, x, enc_img, dec_img, masks, maskB, co["cA"], co["cE"], epss,
+                                    eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,
+                                    self.partD, self.loss_part, dk, Ld)
+        elif use_step:
             # ---- plain bf16, throughput shape: encoder forward + decoder + loss + all backward in ONE launch
             nbE = nbD = self._timed("step_fused", ops.step_fused_bf16, x, self.img_c, masks, maskB, co["cA"], co["cE"], epss,
                                     eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,

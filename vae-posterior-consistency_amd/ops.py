@@ -121,6 +121,22 @@ def decoder_fused(x, dec_img, maskA, maskB, cA, cE, mean, logvar, eps, eps_ml, b
     return nb.value
 
 
+def step_small_max_rows():
+    return int(lib().vpc_step_small_max_rows())
+
+
+def step_small_f32(x, enc_img, dec_img, masks, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE, partD,
+                   loss_part, d, Ld):
+    """Whole fp32 step of a small batch in one launch (16-row tiles, feature tiles split over the waves); returns the
+    number of partial blocks."""
+    n = len(masks)
+    nb = C.c_int(0)
+    check(lib().vpc_step_small_f32(ptr(x), ptr(enc_img), ptr(dec_img), n, ptr_array(masks), ptr_array(maskB), farray(cA),
+                                   farray(cE), ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml, inv_B, x_logvar, ptr(partE),
+                                   ptr(partD), ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, stream_ptr()), "vpc_step_small_f32")
+    return nb.value
+
+
 def step_fused_applicable(B, d, Ld, npass):
     return bool(lib().vpc_step_fused_applicable(int(B), d, Ld, npass))
 
