@@ -369,7 +369,7 @@ int vpc_step_fused_bf16(const float* x, const float* img_c, int npass, const uin
  * own batch sizes (64 / 128, Data/imputation_args*.json) and the per-GPU shards of strong scaling, where the row-tiled kernels
  * are three serial single-tile latencies.  Weights are read from the fp32 images of vpc_build_indices / vpc_pack_weights in
  * global memory; partial blocks and loss terms in the layouts of vpc_encoder_bwd / vpc_decoder_fused.  Plain (not
- * mask-augmented) encoder, obs_dim % 4 == 0; maskB[p] must be NULL or mask[1 - p].
+ * mask-augmented) encoder, obs_dim % 4 == 0, B <= 32 x CUs rows (one workgroup per tile); maskB[p] must be NULL or mask[1 - p].
  * vpc_step_small_max_rows: batches up to this many rows take this path inside FusedTrainer (0 = off; env VPC_STEP_SMALL). */
 long vpc_step_small_max_rows(void);
 int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_img, int npass, const uint8_t* const* mask,

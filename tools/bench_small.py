@@ -2,7 +2,8 @@
 
     python tools/bench_small.py [--batches 64,256,1024,8192,16384,32768] [--steps 300] [--graph]
 
-For every batch size: us / step of FusedTrainer.step with the throughput shape forced (VPC_TILE=128: 128-row tiles, 8
+For every batch size: us / step of FusedTrainer.step with the 16-row N-split kernel forced (VPC_TILE=16: csrc/vpc_small.hip,
+one launch for the whole step), with the throughput shape forced (VPC_TILE=128: 128-row tiles, 8
 waves, both passes looped in the workgroup) and with the small-batch shape forced (VPC_TILE=64: 64-row tiles, one wave
 per SIMD, passes spread over blockIdx.y), device-side draws and Adam included, plus per-kernel HIP-event times.
 Prints one JSON line per (B, shape)."""
@@ -57,7 +58,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     for B in [int(v) for v in a.batches.split(",")]:
-        for tile in ("128", "64"):
+        for tile in ("128", "64", "16"):  # 16 = the N-split kernel (csrc/vpc_small.hip)
             print(json.dumps(run(B, a.dim, tile, a.steps, False)), flush=True)
             if a.graph:
                 print(json.dumps(run(B, a.dim, tile, a.steps, True)), flush=True)

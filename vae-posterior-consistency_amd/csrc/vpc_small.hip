@@ -26,7 +26,7 @@ namespace vpc {
 
 constexpr int SP = 144;             // row pitch of the LDS activation buffers (dwords)
 constexpr int SBUF = 16 * SP;       // one buffer: 16 rows
-enum { B_XQ = 0, B_XP, B_H1Q, B_H1P, B_H2Q, B_H2P, B_ML, B_Z, B_G1, B_G2, B_DP, B_DG2, B_DG1, B_DML, B_DH2, B_DH1, B_COUNT };
+enum { B_XQ = 0, B_XP, B_H1Q, B_H1P, B_H2Q, B_H2P, B_ML, B_Z, B_G1, B_G2, B_DP, B_DG2, B_DG1, B_DMLQ, B_DMLP, B_DH2, B_DH1, B_COUNT };
 constexpr int SMALL_LDS = (B_COUNT * SBUF + WAVES * LOSS_TERMS) * 4;
 static_assert(SMALL_LDS <= 163840, "LDS budget");
 
@@ -61,6 +61,39 @@ __device__ __forceinline__ f32x4 wgrad16(const float* da, int ta, const float* x
     return acc;
 }
 
+// Weight fragments straight from the fp32 image in global memory (the layout of vpc_layout.h: row pitch S dwords, 16-byte slot
+// XOR-swizzled with the row) - REQUESTED one stage ahead of their use (ldW / ldWT), consumed by mmW.  Forward: rows 16 mt + m,
+// one 16-byte load per k-tile; transposed (dgrad): column 16 mt + m, four dword loads per k-tile (tile_fwd / tile_T of
+// vpc_device.h, split into request and use).
+template <int KT, int S>
+__device__ __forceinline__ void ldW(const float* W, int mt, int m, int q, f32x4 (&a)[KT]) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const float* rowp = W + (16 * mt + m) * S;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) a[kt] = *reinterpret_cast<const f32x4*>(rowp + 4 * ((4 * kt + q) ^ (m & MASK)));
+}
+template <int KT, int S, int NK = 4 * KT>
+__device__ __forceinline__ void ldWT(const float* W, int mt, int m, int q, f32x4 (&a)[KT]) {
+    constexpr int MASK = (S / 4 - 1) & 15;
+    const int col = 16 * mt + m, cs = col >> 2, cl = col & 3;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            a[kt][j] = (4 * kt + j < NK) ? W[(16 * kt + r) * S + (((cs ^ (r & MASK)) << 2) | cl)] : 0.f;
+        }
+}
+template <int KT, int NK = 4 * KT>
+__device__ __forceinline__ f32x4 mmW(const f32x4 (&a)[KT], const f32x4 (&in)[KT], f32x4 acc) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * kt + j < NK) acc = VPC_MFMA(a[kt][j], in[kt][j], acc);
+    return acc;
+}
+
 template <int DT>
 __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -84,15 +117,19 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
     const float inv_s2 = expf(-a.x_logvar), half_lv = 0.5f * a.x_logvar;
     constexpr float HL2PI = 0.91893853320467274f;
 
-    // gradient accumulators, 8-wave slot layout (vpc_layout.h)
-    f32x4 acc1[H1T], acc2[H2T], acc3 = zero4(), acc6[H1T], acc5[H2T], acc4 = zero4(), dbacc = zero4();
+    // ONE 16-row tile per workgroup (the host launches one workgroup per tile): the decoder-side gradient accumulators live
+    // through the decoder phases of both passes, are written out, and only then the encoder-side ones come to life for the
+    // encoder backward of both passes - everything those need (x * mask, h1, h2 and the seeds of both passes) is still in LDS.
+    // (All 100 accumulators beside two stages' worth of weight fragments do not fit 256 registers.)
+    f32x4 acc6[H1T], acc5[H2T], acc4 = zero4();
 #pragma unroll
-    for (int t = 0; t < H1T; ++t) { acc1[t] = zero4(); acc6[t] = zero4(); }
+    for (int t = 0; t < H1T; ++t) acc6[t] = zero4();
 #pragma unroll
-    for (int t = 0; t < H2T; ++t) { acc2[t] = zero4(); acc5[t] = zero4(); }
+    for (int t = 0; t < H2T; ++t) acc5[t] = zero4();
     float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    {
+        const int tile = blockIdx.x;
         const long row0 = (long)tile * 16;
         const bool ok = row0 + c < a.B;
         // ---- this wave's column tile of x and of the mask words of both passes (range-checked: rows past B read 0; the last
@@ -115,52 +152,63 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
         auto ld_lat = [&](const float* base) -> f32x4 {  // [B][16] padded latent-width array; NULL reads 0
             return ld_rows(rows_rsrc(base ? base : a.x, row0, base ? a.B : row0, 16), c, 16, 4 * q);
         };
-        __syncthreads();  // the previous tile's last reads of the buffers are done
         int cc = c, qq = q;
         launder(cc, qq);
         // ================================================================ E: encoder forward of both passes
+        // (every stage requests the weight fragments of the NEXT stage before it computes: a stage is ~30 MFMAs, an L2 round
+        // trip as long as that; lds_barrier() leaves those loads in flight)
         for (int p = 0; p < a.npass; ++p) {
             weights();
             float* X = buf(p == 0 ? B_XQ : B_XP);
             float* H1b = buf(p == 0 ? B_H1Q : B_H1P);
             float* H2b = buf(p == 0 ? B_H2Q : B_H2P);
+            f32x4 fW1[DT], fW2[H1T], fW3[H2T], bias1 = zero4();
+            if (w < H1T) {
+                ldW<DT, S1>(W1, w, cc, qq, fW1);
+                bias1 = *reinterpret_cast<const f32x4*>(b1 + 16 * w + 4 * qq);
+            }
             if (w < DT) st_act(X, w, cc, qq, xv * mask_to_f32(p == 0 ? mwq : mwp));  // x.float() * mask  (VAE.py:388)
-            __syncthreads();
+            if (w < H2T) ldW<H1T, 128>(W2, w, cc, qq, fW2);
+            lds_barrier();
             launder(cc, qq);
             if (w < H1T) {
                 f32x4 in[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) in[t] = ld_act(X, t, cc, qq);
-                const f32x4 acc = tile_fwd<DT, S1>(W1, w, in, *reinterpret_cast<const f32x4*>(b1 + 16 * w + 4 * qq), cc, qq);
-                st_act(H1b, w, cc, qq, relu4(acc));
+                st_act(H1b, w, cc, qq, relu4(mmW<DT>(fW1, in, bias1)));
             }
-            __syncthreads();
+            if (w < 2) ldW<H2T, 64>(W3, w, cc, qq, fW3);
+            lds_barrier();
             launder(cc, qq);
             if (w < H2T) {
                 f32x4 in[H1T];
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) in[t] = ld_act(H1b, t, cc, qq);
-                st_act(H2b, w, cc, qq, relu4(tile_fwd<H1T, 128, NK1>(W2, w, in, zero4(), cc, qq)));
+                st_act(H2b, w, cc, qq, relu4(mmW<H1T, NK1>(fW2, in, zero4())));
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
-            if (w < 2) {  // wave 0: mean tile, wave 1: logvar tile -> ML[row][32 p + 16 w ..]
+            if (w < 2) {  // wave 0: mean tile, wave 1: logvar tile -> ML tiles 2 p, 2 p + 1
                 f32x4 in[H2T];
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) in[t] = ld_act(H2b, t, cc, qq);
-                f32x4 o = tile_fwd<H2T, 64, NK2>(W3, w, in, zero4(), cc, qq);
+                f32x4 o = mmW<H2T, NK2>(fW3, in, zero4());
                 if (!ok) o = zero4();  // rows past B: statistics 0
                 st_act(buf(B_ML), 2 * p + w, cc, qq, o);
             }
         }
-        __syncthreads();
-            launder(cc, qq);
+        lds_barrier();
+        launder(cc, qq);
         // ================================================================ per pass: decoder, loss, all backward
         for (int p = 0; p < a.npass; ++p) {
             weights();
             const float* X = buf(p == 0 ? B_XQ : B_XP);
             const float* H1b = buf(p == 0 ? B_H1Q : B_H1P);
             const float* H2b = buf(p == 0 ? B_H2Q : B_H2P);
+            f32x4 fW4[1], fW5[H2T], fW6[H1T], fT6[DT], fT5[H1T], fT4[H2T];
+            float* DML = buf(p == 0 ? B_DMLQ : B_DMLP);
+            if (w < H2T) ldW<1, S4>(W4, w, cc, qq, fW4);
+            if (w < H1T) ldW<H2T, 64>(W5, w, cc, qq, fW5);
             const f32x4 mu = ld_act(buf(B_ML), 2 * p, cc, qq), lv = ld_act(buf(B_ML), 2 * p + 1, cc, qq);
             const f32x4 e = ld_lat(a.eps[p]);
             if (w == 0) {  // z = mean + eps * exp(logvar / 2); z[L] = 1 drives the bias chain
@@ -172,27 +220,28 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 }
                 st_act(buf(B_Z), 0, cc, qq, z);
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
             if (w < H2T) {
                 const f32x4 in[1] = {ld_act(buf(B_Z), 0, cc, qq)};
-                st_act(buf(B_G1), w, cc, qq, relu4(tile_fwd<1, S4>(W4, w, in, zero4(), cc, qq)));
+                st_act(buf(B_G1), w, cc, qq, relu4(mmW<1>(fW4, in, zero4())));
             }
-            __syncthreads();
+            if (w < DT) ldW<H1T, 128>(W6, w, cc, qq, fW6);
+            lds_barrier();
             launder(cc, qq);
             if (w < H1T) {
                 f32x4 in[H2T];
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_G1), t, cc, qq);
-                st_act(buf(B_G2), w, cc, qq, relu4(tile_fwd<H2T, 64, NK2>(W5, w, in, zero4(), cc, qq)));
+                st_act(buf(B_G2), w, cc, qq, relu4(mmW<H2T, NK2>(fW5, in, zero4())));
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
             if (w < DT) {  // output tile w: forward, loss terms, d / d pre-activation
                 f32x4 in[H1T];
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) in[t] = ld_act(buf(B_G2), t, cc, qq);
-                const f32x4 pre = tile_fwd<H1T, 128, NK1>(W6, w, in, zero4(), cc, qq);
+                const f32x4 pre = mmW<H1T, NK1>(fW6, in, zero4());
                 const uint32_t ua = p == 0 ? mwq : mwp;
                 const uint32_t ub = a.mB[p] ? (p == 0 ? mwp : mwq) : ua;  // (host: the second mask is the other pass's)
                 const f32x4 mA = mask_to_f32(ua), mE = mask_to_f32(ua & ~ub);
@@ -211,7 +260,8 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 if (p == 0) { S_A0 += sa; S_E0 += se; } else { S_A1 += sa; }
                 st_act(buf(B_DP), w, cc, qq, dp);
             }
-            __syncthreads();
+            if (w < H1T) ldWT<DT, 128>(W6, w, cc, qq, fT6);  // dg2's fragments
+            lds_barrier();
             launder(cc, qq);
             // ---- dW6~ (wave w: out tile w, 7 in tiles)  |  dg2 = relu'(g2) * (W6~^T dpre) (waves 0-6: tile w)
             if (w < DT) {
@@ -222,9 +272,10 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 f32x4 in[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) in[t] = ld_act(buf(B_DP), t, cc, qq);
-                st_act(buf(B_DG2), w, cc, qq, gate4(tile_T<DT, 128>(W6, w, in, zero4(), cc, qq), ld_act(buf(B_G2), w, cc, qq)));
+                st_act(buf(B_DG2), w, cc, qq, gate4(mmW<DT>(fT6, in, zero4()), ld_act(buf(B_G2), w, cc, qq)));
             }
-            __syncthreads();
+            if (w < H2T) ldWT<H1T, 64, NK1>(W5, w, cc, qq, fT5);  // dg1's fragments
+            lds_barrier();
             launder(cc, qq);
             // ---- dW5~ (wave w: in tile w & 3 of out tiles 4 (w >> 2) .. + 3)  |  dg1 (waves 0-3)
             {
@@ -237,9 +288,10 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 f32x4 in[H1T];
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) in[t] = ld_act(buf(B_DG2), t, cc, qq);
-                st_act(buf(B_DG1), w, cc, qq, gate4(tile_T<H1T, 64, NK1>(W5, w, in, zero4(), cc, qq), ld_act(buf(B_G1), w, cc, qq)));
+                st_act(buf(B_DG1), w, cc, qq, gate4(mmW<H1T, NK1>(fT5, in, zero4()), ld_act(buf(B_G1), w, cc, qq)));
             }
-            __syncthreads();
+            if (w == 4) ldWT<H2T, S4, NK2>(W4, 0, cc, qq, fT4);  // dz's fragments
+            lds_barrier();
             launder(cc, qq);
             // ---- dW4~ (waves 0-3: out tile w)  |  wave 4: dz, KL terms, seeds on (mean | logvar) -> DML
             if (w < H2T) acc4 = wgrad16(buf(B_DG1), w, buf(B_Z), 0, acc4, cc, qq);
@@ -247,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 f32x4 in[H2T];
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_DG1), t, cc, qq);
-                const f32x4 dz = tile_T<H2T, S4, NK2>(W4, 0, in, zero4(), cc, qq);
+                const f32x4 dz = mmW<H2T, NK2>(fT4, in, zero4());
                 const f32x4 mo = two ? ld_act(buf(B_ML), 2 * (1 - p), cc, qq) : zero4();
                 const f32x4 lo = two ? ld_act(buf(B_ML), 2 * (1 - p) + 1, cc, qq) : zero4();
                 f32x4 dmu, dlv;
@@ -296,18 +348,65 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                     dmu[j] = (4 * qq + j < a.L) ? dmu[j] + dz[j] : 0.f;  // columns >= L carry no gradient (dz's column L is db4)
                     dlv[j] = (4 * qq + j < a.L) ? dlv[j] + dz[j] * ef : 0.f;
                 }
-                st_act(buf(B_DML), 0, cc, qq, dmu);
-                st_act(buf(B_DML), 1, cc, qq, dlv);
+                st_act(DML, 0, cc, qq, dmu);
+                st_act(DML, 1, cc, qq, dlv);
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
-            // ---- dW3~ (wave w: out tile w >> 2, in tile w & 3)  |  dh2 (waves 0-3)
-            acc3 = wgrad16(buf(B_DML), w >> 2, H2b, w & 3, acc3, cc, qq);
-            if (w < H2T) {
-                const f32x4 in[2] = {ld_act(buf(B_DML), 0, cc, qq), ld_act(buf(B_DML), 1, cc, qq)};
-                st_act(buf(B_DH2), w, cc, qq, gate4(tile_T<2, 64>(W3, w, in, zero4(), cc, qq), ld_act(H2b, w, cc, qq)));
+        }
+        // ================================================================ decoder partial block and the loss terms
+        {
+            float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
+            const int hi = w >> 2;
+#pragma unroll
+            for (int nt = 0; nt < H1T; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = (w < DT) ? acc6[nt][j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
             }
-            __syncthreads();
+            if (w < H2T) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
+            }
+            const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
+#pragma unroll
+            for (int i = 0; i < LOSS_TERMS; ++i) {
+                const float v = wave_sum_dpp(s[i]);
+                if (lane == 0) red[w * LOSS_TERMS + i] = v;
+            }
+            lds_barrier();
+            if (threadIdx.x < LOSS_TERMS) {
+                double t = 0.0;
+                for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
+                a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
+            }
+        }
+        // ================================================================ encoder backward of both passes
+        f32x4 acc1[H1T], acc2[H2T], acc3 = zero4(), dbacc = zero4();
+#pragma unroll
+        for (int t = 0; t < H1T; ++t) acc1[t] = zero4();
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) acc2[t] = zero4();
+        for (int p = 0; p < a.npass; ++p) {
+            weights();
+            const float* X = buf(p == 0 ? B_XQ : B_XP);
+            const float* H1b = buf(p == 0 ? B_H1Q : B_H1P);
+            const float* H2b = buf(p == 0 ? B_H2Q : B_H2P);
+            const float* DML = buf(p == 0 ? B_DMLQ : B_DMLP);
+            f32x4 fT3[2], fT2[H2T];
+            if (w < H2T) ldWT<2, 64>(W3, w, cc, qq, fT3);    // dh2's fragments
+            if (w < H1T) ldWT<H2T, 128, NK2>(W2, w, cc, qq, fT2);  // dh1's fragments
+            // ---- dW3~ (wave w: out tile w >> 2, in tile w & 3)  |  dh2 (waves 0-3)
+            acc3 = wgrad16(DML, w >> 2, H2b, w & 3, acc3, cc, qq);
+            if (w < H2T) {
+                const f32x4 in[2] = {ld_act(DML, 0, cc, qq), ld_act(DML, 1, cc, qq)};
+                st_act(buf(B_DH2), w, cc, qq, gate4(mmW<2>(fT3, in, zero4()), ld_act(H2b, w, cc, qq)));
+            }
+            lds_barrier();
             launder(cc, qq);
             // ---- dW2~ (waves 0-6: in tile w, 4 out tiles)  |  dh1 (waves 0-6), db1 += column sums of dh1
             if (w < H1T) {
@@ -316,75 +415,45 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
                 f32x4 in[H2T];
 #pragma unroll
                 for (int t = 0; t < H2T; ++t) in[t] = ld_act(buf(B_DH2), t, cc, qq);
-                const f32x4 dh1 = gate4(tile_T<H2T, 128, NK2>(W2, w, in, zero4(), cc, qq), ld_act(H1b, w, cc, qq));
+                const f32x4 dh1 = gate4(mmW<H2T, NK2>(fT2, in, zero4()), ld_act(H1b, w, cc, qq));
                 st_act(buf(B_DH1), w, cc, qq, dh1);
                 dbacc += dh1;  // per-lane (row c) running sums; the sum over the rows happens once, at the end
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
             // ---- dW1 (wave w < DT: in tile w, 7 out tiles)
             if (w < DT) {
 #pragma unroll
                 for (int mt = 0; mt < H1T; ++mt) acc1[mt] = wgrad16(buf(B_DH1), mt, X, w, acc1[mt], cc, qq);
             }
-            __syncthreads();
+            lds_barrier();
             launder(cc, qq);
         }
-    }
-    // ================================================================ partial blocks (vpc_layout.h) and loss terms
-    {
-        float* part = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
+        // ================================================================ encoder partial block
+        {
+            float* part = a.partE + (long)blockIdx.x * ENC_PART + (long)w * GREGS * 64 + lane;
 #pragma unroll
-        for (int mt = 0; mt < H1T; ++mt)
+            for (int mt = 0; mt < H1T; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = (w < DT) ? acc1[mt][j] : 0.f;
+                for (int j = 0; j < 4; ++j) part[(4 * mt + j) * 64] = (w < DT) ? acc1[mt][j] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < H2T; ++mt)
+            for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = (w < H1T) ? acc2[mt][j] : 0.f;
+                for (int j = 0; j < 4; ++j) part[(28 + 4 * mt + j) * 64] = (w < H1T) ? acc2[mt][j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
-        // db1[16 w + 4 q + j] = sum over the 16 rows (lanes c) of dbacc: DPP butterfly inside each 16-lane row
+            for (int j = 0; j < 4; ++j) part[(44 + j) * 64] = acc3[j];
+            // db1[16 w + 4 q + j] = sum over the 16 rows (lanes c) of dbacc: DPP butterfly inside each 16-lane row
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = dbacc[j];
-            v += dpp_mov<0xB1>(v);
-            v += dpp_mov<0x4E>(v);
-            v += dpp_mov<0x141>(v);
-            v += dpp_mov<0x140>(v);
-            if (c == 0 && w < H1T) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 16 * w + 4 * q + j] = v;
+            for (int j = 0; j < 4; ++j) {
+                float v = dbacc[j];
+                v += dpp_mov<0xB1>(v);
+                v += dpp_mov<0x4E>(v);
+                v += dpp_mov<0x141>(v);
+                v += dpp_mov<0x140>(v);
+                if (c == 0 && w < H1T) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 16 * w + 4 * q + j] = v;
+            }
+            if (w == 7 && lane < 16) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 112 + lane] = 0.f;
         }
-        if (w == 7 && lane < 16) a.partE[(long)blockIdx.x * ENC_PART + WAVES * GREGS * 64 + 112 + lane] = 0.f;
-    }
-    {
-        float* part = a.partD + (long)blockIdx.x * DEC_PART + (long)(w & 3) * DEC_GREGS * 64 + lane;
-        const int hi = w >> 2;
-#pragma unroll
-        for (int nt = 0; nt < H1T; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[(28 * hi + 4 * nt + j) * 64] = (w < DT) ? acc6[nt][j] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* p5 = a.partD + (long)blockIdx.x * DEC_PART + (long)i * DEC_GREGS * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p5[(56 + 16 * hi + 4 * (w & 3) + j) * 64] = (i < 3 || w < 4) ? acc5[i][j] : 0.f;
-        }
-        if (w < H2T) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[(88 + j) * 64] = acc4[j];
-        }
-    }
-    const float s[LOSS_TERMS] = {S_A0, S_E0, S_A1, S_kl0q, S_kl0p, S_klr, S_zll, 0.f};
-#pragma unroll
-    for (int i = 0; i < LOSS_TERMS; ++i) {
-        const float v = wave_sum_dpp(s[i]);
-        if (lane == 0) red[w * LOSS_TERMS + i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < LOSS_TERMS) {
-        double t = 0.0;
-        for (int k = 0; k < WAVES; ++k) t += (double)red[k * LOSS_TERMS + threadIdx.x];
-        a.loss_part[(long)blockIdx.x * LOSS_TERMS + threadIdx.x] = t;
     }
 }
 
@@ -392,14 +461,14 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
 
 using namespace vpc;
 
-// Rows up to which the library runs an fp32 step through vpc_step_small_f32 (0 = never): by default batches of up to 4
-// sixteen-row tiles per workgroup in one round of CUs.  VPC_TILE=16 forces this path for every batch, VPC_TILE=64 / 128 (the
+// Rows up to which the library runs an fp32 step through vpc_step_small_f32 (0 = never): by default one round of workgroups
+// (16 rows x CUs).  The kernel takes up to 2 x CUs tiles (the partial-block buffers' size).  VPC_TILE=16 forces this path for every batch, VPC_TILE=64 / 128 (the
 // row-tiled workgroup shapes) switch it off, VPC_STEP_SMALL=n sets the row limit (A/B runs, tests).
 extern "C" long vpc_step_small_max_rows(void) {
-    long lim = 64L * num_cus();
+    long lim = 16L * num_cus();
     if (const char* e = getenv("VPC_TILE")) {
         const int v = atoi(e);
-        if (v == 16) lim = 1L << 40;
+        if (v == 16) lim = 32L * num_cus();
         if (v == 64 || v == 128) lim = 0;
     }
     if (const char* e = getenv("VPC_STEP_SMALL")) lim = atol(e);
@@ -428,9 +497,9 @@ extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const fl
     }
     for (int p = 0; p < npass; ++p)  // the second loss mask of a pass must be the other pass's mask (as vpc_step_fused_bf16)
         if (a.mB[p] && (npass != 2 || a.mB[p] != a.m[1 - p])) return VPC_ERR_ARG;
+    if ((B + 15) / 16 > 2L * num_cus()) return VPC_ERR_SHAPE;  // one workgroup per 16-row tile, at most 2 x CUs partial blocks
     a.ntiles = (int)((B + 15) / 16);
-    const int ncu = num_cus();
-    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    const int grid = a.ntiles;
     if (nblocks_out) *nblocks_out = grid;
     hipStream_t s = (hipStream_t)stream;
 #define VPC_CASE(T)                                                                                        \

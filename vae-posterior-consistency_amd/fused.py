@@ -258,7 +258,7 @@ class FusedTrainer:
         masks = [mask, mask_p] if two else [mask]
         epss = [eq, ep] if two else [eq]
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
-        use_small = (not self.prec) and not lay.mask_augm and B <= ops.step_small_max_rows()
+        use_small = (not self.prec) and not lay.mask_augm and B <= ops.step_small_max_rows()  # (<= 32 x CUs rows)
         self._used_step_small = use_small
         if use_small:
             # ---- fp32, small batch: the whole step in ONE launch, 16-row tiles with the feature tiles split over the waves
