@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracles run thousands of tiny matmuls (the reward restatement: 4 (d - 1) M encoder calls): torch's default of one
+    # thread per host core (128 on a GPU box whose job owns a 16-core share) oversubscribes and has been seen to take minutes
+    torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
 
 
 def pytest_collection_modifyitems(config, items):
