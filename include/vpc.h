@@ -320,6 +320,33 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
                 unsigned long long offset_eps, const long long* state, long elem_lo, long eps_rows_local,
                 long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream);
 
+/* ---- layer-fused K-fold decoder of the regularised MNAR step, plain bf16 MFMA inputs (csrc/vpc_nmdec.hip) ----------
+ * Replaces, for REG_notMIWAE_v2 at obs_dim = 128 (latent_dim <= 15, 4 <= K <= 64; hidden width 128), the launches
+ *   vpc_nm_sample -> 3 x vpc_linear_fwd -> vpc_nm_loss -> 3 x (vpc_linear_wgrad, vpc_linear_dgrad) -> vpc_nm_sample_bwd
+ * of one training step with precision = 2 (src/models/VAE.py:2382-2396 K-fold rsample + decoder, :2398-2471 loss, and
+ * their autograd, src/experiment_main/train.py:115): the K replicas of a few data rows are one workgroup tile, and no
+ * array of B * K rows crosses HBM.  Same mathematics, gradient weights and bf16 rounding points as that chain, except
+ * that ELU' is taken from the bf16-rounded activation and the per-row terms of the missingness model's dW / db are
+ * rounded to bf16 before their sum over rows (tests/test_nmdec.py; oracle/notmiwae_oracle.py mirrors both).
+ *   vpc_nmdec_applicable     1 when vpc_nmdec_step covers the shape (VPC_NMDEC=0 in the environment: never)
+ *   vpc_nmdec_layout         floats of the weight image, floats of one partial block, most workgroups of a launch
+ *   vpc_nmdec_build_indices  HOST tables over the model's flat parameter buffer (n entries, order
+ *                            [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]): pack_idx as
+ *                            vpc_step_pack_weights_bf16 reads it (INT_MIN: not in the image - the encoder), grad_idx =
+ *                            position of the parameter's gradient inside a partial block (-1: not produced here)
+ *   vpc_nmdec_step           heads [2 B][ldh] = encoder (mean | logvar) of the q rows, then of the p rows; eps [2 B K][L];
+ *                            dht [2 B][2 L] receives d loss / d heads (sum over K of dz + the analytic KL gradients);
+ *                            grad (flat, n entries) receives the entries grad_idx names (fixed-order sum of the blocks);
+ *                            out8 / loss_f32 / accum / state / rng_inc / B_global / alpha as vpc_nm_loss.
+ *                            part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (caller-owned). */
+int vpc_nmdec_applicable(long B, int K, int d, int L);
+int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks);
+int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n);
+int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
+                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, float* grad, int n,
+                   double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
+                   int K, int d, int L, double alpha, void* stream);
+
 /* ---- PNP / EDDI encoder front-end (Reg_EDDI / vanilla_EDDI, src/models/VAE.py:719-733, 903-917) ----------
  * agg[b] = sum_j mask[b][j] relu(W [x_bj, x_bj E_j, t_j] + c), W = pnp_encoder1.0.weight [K][2+K], c its bias,
  * E = type_pars1 [d][K], t = type_bias1 [d].  The layer folds per feature into pre = x_bj A_j + C_j
@@ -344,7 +371,8 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
  * plain (not mask-augmented) encoder, any batch (the grid is min(tiles, CUs) workgroups looping over their tiles).
  * Takes its own weight image (all six layers, bf16, 98.5 KB): vpc_step_layout_bf16 gives its size in floats and the
  * kernel's dynamic-LDS bytes; vpc_step_build_indices_bf16 fills HOST arrays pack_idx_c[n_params] / img_template_c[floats];
- * vpc_step_pack_weights_bf16 writes img_c from the flat parameters (after every optimiser step).
+ * vpc_step_pack_weights_bf16 writes img_c from the flat parameters (after every optimiser step): entry i of pack_idx_c >= 0 is
+ * the u16 position of parameter i inside the image, < 0 the dword -(idx + 1) of a value that stays fp32, INT_MIN = skip.
  * vpc_step_fused_bf16: arguments as vpc_decoder_fused (mask[p] is the encoder mask AND the first loss mask of pass p;
  * eps[p] [B][16] padded rows, eps_ml likewise); partE / partD / loss_partials are written in the layouts of
  * vpc_encoder_bwd / vpc_decoder_fused (*nblocks_out blocks each), so vpc_reduce_step(_adam) consumes them unchanged.

@@ -95,8 +95,8 @@ class _RoundedLinear(torch.autograd.Function):
     unrounded dY.  Run it on float64 tensors: the accumulation is then exact and only the operand rounding is modelled."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mode):
-        ctx.mode, ctx.shape = mode, x.shape
+    def forward(ctx, x, w, b, mode, db_rounded=False):
+        ctx.mode, ctx.shape, ctx.db_rounded = mode, x.shape, db_rounded
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, w)
         return (_mm_mode(x2, w.t(), mode) + b).reshape(*x.shape[:-1], w.shape[0])
@@ -106,22 +106,65 @@ class _RoundedLinear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = _mm_mode(dy2, w, ctx.mode).reshape(ctx.shape)
-        return dx, _mm_mode(dy2.t(), x2, ctx.mode), dy2.sum(0), None
+        # db_rounded (the layer-fused decoder kernel, csrc/vpc_nmdec.hip): db is the column sum of the STAGED bf16 dY
+        db = (_bf16_t(dy2) if ctx.db_rounded else dy2).sum(0)
+        return dx, _mm_mode(dy2.t(), x2, ctx.mode), db, None, None
 
 
-def rounded_linear(mode):
+def rounded_linear(mode, db_rounded=False):
     """F.linear replacement for NMTorchPort(linear=...): the bf16-emulating oracle of the MNAR step."""
-    return lambda x, w, b: _RoundedLinear.apply(x, w, b, mode)
+    return lambda x, w, b: _RoundedLinear.apply(x, w, b, mode, db_rounded)
+
+
+class _EluRoundedGate(torch.autograd.Function):
+    """ELU whose derivative is taken from the bf16-rounded OUTPUT (1 where it is > 0, else output + 1): the layer-fused
+    decoder kernel keeps its hidden activations only as packed bf16 MFMA operands (csrc/vpc_nmdec.hip, elu_gate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = F.elu(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        yr = _bf16_t(ctx.saved_tensors[0])
+        return dy * torch.where(yr > 0, torch.ones_like(yr), yr + 1)
+
+
+class _MissLogitsRounded(torch.autograd.Function):
+    """logits = -softplus(W) (mixed - b) of the self-masking model (VAE.py:2424-2427) with the row terms of dW / db rounded to
+    bf16 before they are summed over the rows - the layer-fused decoder kernel sums them as MFMAs of staged bf16 operands."""
+
+    @staticmethod
+    def forward(ctx, W, b, mixed):
+        ctx.save_for_backward(W, b, mixed)
+        return -F.softplus(W) * (mixed - b)
+
+    @staticmethod
+    def backward(ctx, g):
+        W, b, mixed = ctx.saved_tensors
+        sp, sg = F.softplus(W), torch.sigmoid(W)
+        red = tuple(range(g.dim() - 1))
+        gW = -sg * _bf16_t(g * (mixed - b)).sum(red).reshape(W.shape)
+        gb = sp * _bf16_t(g).sum(red).reshape(b.shape)
+        return gW, gb, -sp * g
 
 
 class NMTorchPort:
     """Functional restatement over a dict of tensors (keys NM_KEYS).  ``regularised`` selects REG_notMIWAE_v2.
-    ``linear``: the affine layer (default F.linear; `rounded_linear("bf16")` models the bf16 GEMM kernels)."""
+    ``linear``: the affine layer (default F.linear; `rounded_linear("bf16")` models the bf16 GEMM kernels).
+    ``fused_decoder``: model the rounding points of the layer-fused decoder kernel (csrc/vpc_nmdec.hip) on the decoder side:
+    bias gradients from the bf16-rounded dY, ELU' from the bf16-rounded activation, bf16 row terms of the missingness
+    model's dW / db (the encoder keeps `linear`: it stays on the GEMM kernels)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool, linear=None):
+    def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool, linear=None, fused_decoder=False):
         self.p = params
         self.L, self.K, self.reg = L, K, regularised
         self.lin = linear or F.linear
+        self.fused_decoder = fused_decoder
+        self.lin_dec = rounded_linear("bf16", db_rounded=True) if fused_decoder else self.lin
+        self.elu_dec = _EluRoundedGate.apply if fused_decoder else F.elu
 
     # VAE.py:2378-2391 / :2749-2765
     def encoder(self, x, mask, eps: Optional[torch.Tensor]):
@@ -139,10 +182,11 @@ class NMTorchPort:
     # VAE.py:2393-2397 / :2767-2772
     def decoder(self, z):
         p = self.p
-        g = F.elu(self.lin(z, p["seq_decoder.0.weight"], p["seq_decoder.0.bias"]))
-        g = F.elu(self.lin(g, p["seq_decoder.2.weight"], p["seq_decoder.2.bias"]))
-        xm = torch.sigmoid(self.lin(g, p["x_mean.0.weight"], p["x_mean.0.bias"]))
-        xl = F.hardtanh(self.lin(g, p["x_logvar.0.weight"], p["x_logvar.0.bias"]), -10.0, 0.0)
+        lin, elu = self.lin_dec, self.elu_dec
+        g = elu(lin(z, p["seq_decoder.0.weight"], p["seq_decoder.0.bias"]))
+        g = elu(lin(g, p["seq_decoder.2.weight"], p["seq_decoder.2.bias"]))
+        xm = torch.sigmoid(lin(g, p["x_mean.0.weight"], p["x_mean.0.bias"]))
+        xl = F.hardtanh(lin(g, p["x_logvar.0.weight"], p["x_logvar.0.bias"]), -10.0, 0.0)
         return xm, xl
 
     @staticmethod
@@ -151,7 +195,10 @@ class NMTorchPort:
 
     def _logp_s(self, x3, m3, xm):  # VAE.py:2413-2432 'selfmasking_known'
         mixed = xm * (1 - m3) + x3 * m3
-        logits = -F.softplus(self.p["W"]) * (mixed - self.p["b"])
+        if self.fused_decoder:
+            logits = _MissLogitsRounded.apply(self.p["W"], self.p["b"], mixed)
+        else:
+            logits = -F.softplus(self.p["W"]) * (mixed - self.p["b"])
         return torch.sum(m3 * logits - F.softplus(logits), 2)  # Bernoulli(logits).log_prob(m)
 
     def reg_forward(self, x, mask, mask_p, eps_q, eps_p):  # VAE.py:2500-2505 (p outputs first)

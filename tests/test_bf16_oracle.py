@@ -184,15 +184,18 @@ def test_mnar_trainer_vs_emulating_oracle(prec, kind):
     m = (torch.rand(B, d, generator=g) < 0.7).float()
     mp = m * (torch.rand(B, d, generator=g) < 0.5).float()
     eps = torch.randn(2, B, K, L, generator=g)
-    port = NO.NMTorchPort(p, L, K, kind == "reg", linear=NO.rounded_linear(prec))
+    tr = nm.NMTrainer(model, precision=prec)
+    tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda() if kind == "reg" else None, eps=eps.cuda(), alpha=0.5, p_missingness=50)
+    # (the regularised class in plain bf16 runs the layer-fused decoder kernel at this shape: tests/test_nmdec.py - the port then
+    # models that kernel's rounding points on the decoder side)
+    assert tr.use_nmdec == (kind == "reg" and prec == "bf16")
+    port = NO.NMTorchPort(p, L, K, kind == "reg", linear=NO.rounded_linear(prec), fused_decoder=tr.use_nmdec)
     xd, md, mpd, ed = x.double(), m.double(), mp.double(), eps.double()
     if kind == "reg":
         ref = port.reg_loss(xd, port.reg_forward(xd, md, mpd, ed[0], ed[1]), md, mpd, alpha=0.5)
     else:
         ref = port.van_loss(xd, port.van_forward(xd, md, ed[0]), md, ed[1])
     ref.backward()
-    tr = nm.NMTrainer(model, precision=prec)
-    tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda() if kind == "reg" else None, eps=eps.cuda(), alpha=0.5, p_missingness=50)
     assert abs(tr.loss_value() - ref.item()) <= LOSS_TOL * abs(ref.item()), (tr.loss_value(), ref.item())
     for k, prm in model.named_parameters():
         if k in p and p[k].grad is not None:

@@ -1,0 +1,160 @@
+"""Layer-fused K-fold decoder of the regularised MNAR step (csrc/vpc_nmdec.hip; REG_notMIWAE_v2, src/models/VAE.py:2382-2471).
+
+CPU: the host-side index tables (every decoder / missingness parameter has exactly one place in the weight image and one in
+a partial block; the encoder's are skipped) and the oracle's model of the kernel's rounding points.
+GPU: NMTrainer(precision="bf16") - which runs the fused kernel at obs_dim 128 - against the float64 port of the oracle with
+the SAME operand rounding (loss <= 1e-5 rel, gradients <= 2e-3 of max: the Hardtanh gate, see tests/test_bf16_oracle.py),
+on full, ragged and multi-tile batches, other K / latent sizes, and against the GEMM chain it replaces."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import notmiwae_oracle as NO
+
+LOSS_TOL, GRAD_TOL = 1e-5, 2e-3
+HID = 128
+INT_MIN = -2 ** 31
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def _tables(d, L):
+    from vpc_amd import _lib
+    n_enc = HID * d + HID + HID * HID + HID + 2 * L * HID + 2 * L
+    n_dec = HID * L + HID + HID * HID + HID + 2 * d * HID + 2 * d
+    n = 2 * d + n_enc + n_dec
+    pidx, gidx = np.empty(n, np.int32), np.empty(n, np.int32)
+    rc = _lib.lib().vpc_nmdec_build_indices(d, L, HID, pidx.ctypes.data_as(_lib.P), gidx.ctypes.data_as(_lib.P), n)
+    assert rc == 0
+    return pidx, gidx, n_enc, n_dec
+
+
+def test_index_tables_cpu():
+    from vpc_amd import _lib
+    d, L = 128, 10
+    pidx, gidx, n_enc, n_dec = _tables(d, L)
+    nimg, npart, nblk = C.c_int(), C.c_long(), C.c_int()
+    assert _lib.lib().vpc_nmdec_layout(128, 20, d, L, C.byref(nimg), C.byref(npart), C.byref(nblk)) == 0
+    enc = slice(2 * d, 2 * d + n_enc)
+    assert (pidx[enc] == INT_MIN).all() and (gidx[enc] == -1).all()
+    own = np.r_[0:2 * d, 2 * d + n_enc:2 * d + n_enc + n_dec]
+    p, g = pidx[own].astype(np.int64), gidx[own].astype(np.int64)
+    assert (p != INT_MIN).all() and (g >= 0).all()
+    # bf16 entries: u16 positions inside the image; fp32 entries: dword -(idx + 1); no two parameters share a place
+    u16 = p[p >= 0]
+    f32 = -(p[p < 0] + 1)
+    assert len(u16) == HID * L + HID * HID + 2 * d * HID and len(f32) == 2 * d + 2 * HID + 2 * d
+    assert u16.max() < 2 * nimg.value and f32.max() < nimg.value
+    assert len(np.unique(u16)) == len(u16) and len(np.unique(f32)) == len(f32)
+    assert not np.intersect1d(u16 // 2, f32).size
+    assert g.max() < npart.value and len(np.unique(g)) == len(g)
+    # shapes the kernel does not cover
+    assert _lib.lib().vpc_nmdec_applicable(128, 20, 14, 10) == 0
+    assert _lib.lib().vpc_nmdec_applicable(128, 2, 128, 10) == 0
+    assert _lib.lib().vpc_nmdec_applicable(128, 20, 128, 10) == 1
+
+
+def _problem(d, L, K, B, seed=5):
+    torch.manual_seed(seed)
+    p = {k: v.double() for k, v in NO.nm_init_params(d, L, seed=seed).items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.rand(B, d, generator=g)
+    m = (torch.rand(B, d, generator=g) < 0.7).float()
+    mp = m * (torch.rand(B, d, generator=g) < 0.5).float()
+    eps = torch.randn(2, B, K, L, generator=g)
+    return p, x, m, mp, eps
+
+
+def _oracle_step(p, x, m, mp, eps, L, K, alpha, fused):
+    pp = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    port = NO.NMTorchPort(pp, L, K, True, linear=NO.rounded_linear("bf16"), fused_decoder=fused)
+    xd, md, mpd, ed = x.double(), m.double(), mp.double(), eps.double()
+    loss = port.reg_loss(xd, port.reg_forward(xd, md, mpd, ed[0], ed[1]), md, mpd, alpha=alpha)
+    loss.backward()
+    return loss.item(), {k: v.grad.numpy() for k, v in pp.items() if v.grad is not None}
+
+
+def test_oracle_fused_rounding_model_cpu():
+    """The fused-decoder rounding model changes the bf16 oracle's gradients by rounding-sized amounts only, never the loss."""
+    d, L, K, B = 128, 10, 20, 6
+    p, x, m, mp, eps = _problem(d, L, K, B)
+    l0, g0 = _oracle_step(p, x, m, mp, eps, L, K, 0.5, False)
+    l1, g1 = _oracle_step(p, x, m, mp, eps, L, K, 0.5, True)
+    assert l0 == l1
+    worst = max(rel(g1[k], g0[k]) for k in g0)
+    assert 0 < worst < 5e-3, worst
+
+
+def _trainer_vs_oracle(d, L, K, B, alpha, seed=5):
+    from vpc_amd import notmiwae as nm
+    p, x, m, mp, eps = _problem(d, L, K, B, seed)
+    model = nm.REG_notMIWAE_v2(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1)
+    model.load_state_dict({k: v.float() for k, v in p.items()}, strict=False)
+    model = model.cuda()
+    tr = nm.NMTrainer(model, precision="bf16")
+    tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda(), eps=eps.cuda(), alpha=alpha, p_missingness=50)
+    fused = tr.use_nmdec
+    ref, gref = _oracle_step(p, x, m, mp, eps, L, K, alpha, fused)
+    assert abs(tr.loss_value() - ref) <= LOSS_TOL * abs(ref), (tr.loss_value(), ref)
+    for k, prm in model.named_parameters():
+        if k in gref:
+            e = rel(prm.grad.cpu().numpy(), gref[k])
+            # (a handful of data rows: one Hardtanh gate that flips within fp32 accumulation error of the clamp moves an entry
+            # by O(1 / (B K)) of the total - the bound scales accordingly below 16 rows)
+            assert e < (GRAD_TOL if B >= 16 else 2 * GRAD_TOL), (k, e, fused)
+    return tr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,L,alpha", [(128, 20, 10, 0.5), (37, 20, 10, 1.0), (3, 20, 10, 0.3), (1000, 20, 10, 0.5),
+                                         (50, 7, 5, 0.5), (20, 64, 15, 0.7), (33, 4, 1, 0.5)])
+def test_fused_decoder_vs_emulating_oracle(B, K, L, alpha):
+    """config 3's shape (d = 128, K = 20, batch 128), ragged last tiles (37 = 12 x 3 + 1 data rows per pass), a batch smaller
+    than one tile, many tiles per workgroup (1000 rows -> 668 tiles on 256 CUs), and the extremes of K / latent size the
+    kernel accepts (K = 7: 9 data rows per tile; K = 64: one; K = 4: 16)."""
+    tr = _trainer_vs_oracle(128, L, K, B, alpha)
+    assert tr.use_nmdec
+
+
+@pytest.mark.gpu
+def test_gemm_chain_still_matches_its_oracle(monkeypatch):
+    """VPC_NMDEC=0 keeps the GEMM chain (the form every other precision / shape / the un-regularised class runs)."""
+    monkeypatch.setenv("VPC_NMDEC", "0")
+    tr = _trainer_vs_oracle(128, 10, 20, 128, 0.5)
+    assert not tr.use_nmdec
+
+
+@pytest.mark.gpu
+def test_fused_and_gemm_trajectories_agree(monkeypatch):
+    """Five optimiser steps with device-side draws (same Philox streams): the two forms of the bf16 step stay together to
+    bf16-rounding level, and the fused form leaves the epoch total / step counters as the GEMM form does."""
+    from vpc_amd import notmiwae as nm
+    d, L, K, B = 128, 10, 20, 128
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, d, generator=g).cuda()
+    m = (torch.rand(B, d, generator=g) < 0.7).float().cuda()
+    runs = {}
+    for form in ("fused", "gemm"):
+        if form == "gemm":
+            monkeypatch.setenv("VPC_NMDEC", "0")
+        torch.manual_seed(3)
+        model = nm.REG_notMIWAE_v2(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, precision="bf16", seed=11)
+        losses = []
+        for _ in range(5):
+            tr.step(x, m, alpha=0.5, p_missingness=50)
+            losses.append(tr.loss_value())
+        assert tr.use_nmdec == (form == "fused")
+        runs[form] = (losses, tr.epoch_total(), model.flatten_parameters().detach().cpu().numpy().copy())
+    lf, lg = np.array(runs["fused"][0]), np.array(runs["gemm"][0])
+    assert np.all(np.abs(lf - lg) <= 2e-4 * np.abs(lg)), (lf, lg)
+    assert abs(runs["fused"][1] - runs["gemm"][1]) <= 2e-4 * abs(runs["gemm"][1])
+    # (parameters: Adam turns a rounding-sized difference of a near-zero gradient into a full +-lr step, so after five steps
+    # they may differ by up to 2 * 5 * lr where a gradient changes sign - bounded, not compared tightly)
+    assert float(np.max(np.abs(runs["fused"][2] - runs["gemm"][2]))) <= 2 * 5 * 1e-3
+    assert lf[-1] < lf[0]

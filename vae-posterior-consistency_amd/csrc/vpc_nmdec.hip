@@ -1,0 +1,762 @@
+// Layer-fused K-fold decoder of the MNAR step, plain bf16 MFMA inputs (gfx950): reparameterisation -> decoder (two ELU layers +
+// the Sigmoid | Hardtanh heads) -> importance-weighted bound with the self-masking missingness model -> decoder backward (every
+// dgrad and wgrad) -> reduction of dz over the K replicas, for the K replicas of a few data rows per workgroup tile, in ONE
+// launch.  Nothing of size B * K crosses HBM (the GEMM form of the same step moves 35 GB of activations at B = 65 536).
+//
+// Reference semantics: REG_notMIWAE_v2 src/models/VAE.py:2382-2396 (K-fold rsample, decoder), :2398-2471 (loss) and the autograd of
+// src/experiment_main/train.py:115.  Same mathematics, gradient weights and rounding points (oracle/notmiwae_oracle.py,
+// rounded_linear("bf16") + elu_gate_rounded) as  vpc_nm_sample -> 3 x vpc_linear_fwd -> vpc_nm_loss -> 3 x (vpc_linear_wgrad,
+// vpc_linear_dgrad) -> vpc_nm_sample_bwd  with precision = 2, which it replaces for the regularised model at obs_dim = 128.
+//
+// Workgroup: 4 waves (one per SIMD, 512 registers each), one 16-row slice of the 64-row tile per wave.  A tile holds the K replicas
+// of nb = 64 / K data rows (rows r = bl * K + k; the last 64 - nb K rows are padding: K = 20 -> 60 of 64 rows carry work); the
+// stacked passes (q rows, then p rows) are tiled separately, so a tile's pass is uniform.
+// LDS (160 256 of 163 840 bytes): one bf16 image of the three layers in the compact layout of vpc_step.hip (c_elem<KP>: W1 128 x 32,
+// W2 128 x 128, Wx 256 x 128) + fp32 biases + W, b of the missingness model and their softplus / sigmoid (110.6 KB), 24 staging
+// slots of [64 rows x 16 features] bf16 for the wgrad operands (48 KB, bf_stage layout of vpc_bf16.h), 64 floats for the K-coupling.
+// Registers: 248 gradient accumulators per lane (dWx 128, dW2 64, dW1 8, the three bias gradients 32 and dW | db of the missingness
+// model 16 - column sums come from the same staged operands as MFMAs against a constant-ones B operand), the head outputs of the
+// lane's row (64) across the log-sum-exp over K.
+// Staging rounds per tile (write - barrier - transposed reads + MFMA - barrier), slots in brackets:
+//   R1a dWx[xm rows] = Gxm^T g2, dbx, db(miss) = e1^T 1   [0-7 | 8-15 | 16-23]
+//   R1b dWx[xl rows] = Gxl^T g2, dbx, dW(miss) = e2^T 1   [0-7 | (8-15 kept) | 16-23]
+//   R2  dW2 = dg2^T g1, db2 [0-7 | 8-15]        R3  dW1 = dg1^T z, db1 [0-7 | 8]
+// and two exchanges through LDS: the rows' bound terms l_w (softmax over the K replicas of a data row sits in 2-3 different waves)
+// and dz (summed over K by one lane per (data row, latent), which also adds the analytic KL gradients).
+#include "vpc_abi_internal.h"
+#include "vpc_device.h"
+#include "vpc_bf16.h"
+#include "vpc_dec_args.h"
+#include <climits>
+#include <cstring>
+
+namespace vpc {
+
+// compact image helpers (same layout as vpc_step.hip; kept local: that file's are tied to its layer constants)
+template <int KP>
+VPC_HD constexpr int nd_key(int row) {
+    return KP == 128 ? ((((row >> 1) & 3) << 2) | (((row >> 3) & 1) << 1) | (row & 1))
+                     : ((row / (128 / KP)) & (KP / 8 - 1));
+}
+template <int KP>
+VPC_HD constexpr int nd_elem(int row, int f) {  // u16 index of (row, input feature f) inside a layer image
+    return row * KP + (((4 * (f >> 5) + ((f >> 2) & 3)) ^ nd_key<KP>(row)) << 3) + 4 * ((f >> 4) & 1) + (f & 3);
+}
+
+constexpr int ND_WAVES = 4, ND_THREADS = 256, ND_ROWS = 64, ND_HID = 128, ND_HT = 8;
+constexpr int ND_FT = 24;                                  // staging slots per row
+constexpr int ND_ST_DW = (ND_ROWS / 8) * ND_FT * 64;       // 12 288 dwords
+constexpr int ND_NSTAT = 5;
+// dword offsets inside the image (global and LDS): bf16 layers, fp32 biases, raw W / b of the missingness model; LDS only: their
+// softplus / sigmoid
+struct NdImg {
+    static constexpr int oW1 = 0, oW2 = oW1 + ND_HID * 16, oWx = oW2 + ND_HID * 64, ob1 = oWx + 256 * 64, ob2 = ob1 + ND_HID,
+                         obx = ob2 + ND_HID, oWm = obx + 256, oBm = oWm + 128, total = oBm + 128, oSP = total, oSG = oSP + 128,
+                         lds_total = oSG + 128;
+};
+constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_ROWS + 2 * ND_WAVES * ND_NSTAT) * 4;
+static_assert(ND_LDS <= 163840, "LDS budget");
+// partial block: [248 accumulator registers][256 threads]
+constexpr int ND_REGS = 248, ND_PART = ND_REGS * ND_THREADS;
+constexpr int R_X = 0, R_BX = 128, R_2 = 144, R_B2 = 208, R_1 = 216, R_B1 = 224, R_WB = 232;
+
+typedef bf16x8 Op;
+
+struct NmdArgs {
+    const float* img;
+    const float* x; const float* m; const float* mp;   // [B][d]
+    const float* heads; long ldh;                      // [2 B][mean L | logvar L]: q rows, then p rows
+    const float* eps;                                  // [2 B K][L]
+    float* dht;                                        // [2 B][2 L]: gradient w.r.t. the encoder heads
+    float* part;                                       // [blocks][ND_PART]
+    double* stat_part;                                 // [blocks][ND_NSTAT]
+    int B, K, d, L, nb, tiles_per_pass, ntiles;
+    float oq, op, oe, cr, kq, kp, cd;
+    int dbg;
+};
+
+__device__ __forceinline__ Op nd_pack2(f32x4 t0, f32x4 t1) {
+    const u32x4 h = {pk_bf16(t0[0], t0[1]), pk_bf16(t0[2], t0[3]), pk_bf16(t1[0], t1[1]), pk_bf16(t1[2], t1[3])};
+    return __builtin_bit_cast(Op, h);
+}
+template <int KP>
+__device__ __forceinline__ Op nd_wfrag(const float* W, int mt, int kb, int m, int q) {
+    return __builtin_bit_cast(Op, *reinterpret_cast<const f32x4*>(W + (16 * mt + m) * (KP / 2) + 4 * ((4 * kb + q) ^ nd_key<KP>(m))));
+}
+template <int KP>
+__device__ __forceinline__ Op nd_wfrag_T(const float* W, int mt, int kb, int lane) {
+    const int q = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 32 * kb + 4 * q + rr, r1 = r0 + 16;
+    const int pi = 4 * (mt >> 1) + pp, e = 2 * (mt & 1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 h0 = ds_tr16(W + r0 * (KP / 2) + 4 * (pi ^ nd_key<KP>(r0)) + e);
+    const s16x4 h1 = ds_tr16(W + r1 * (KP / 2) + 4 * (pi ^ nd_key<KP>(r1)) + e);
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    return __builtin_bit_cast(Op, h);
+}
+// forward layer, TWO out tiles per step (two independent MFMA chains: one wave per SIMD has nothing else to cover the dependent
+// latency with); the fragments of the next pair are requested behind the MFMAs of this one
+template <int KP, int KB, int NT, typename F>
+__device__ __forceinline__ void nd_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink) {
+    static_assert(NT % 2 == 0, "");
+    Op c0[KB], c1[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag<KP>(W, 0, kb, m, q); c1[kb] = nd_wfrag<KP>(W, 1, kb, m, q); }
+#pragma unroll
+    for (int mt = 0; mt < NT; mt += 2) {
+        f32x4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { a0 = VPC_MFMA_BF(c0[kb], in[kb], a0); a1 = VPC_MFMA_BF(c1[kb], in[kb], a1); }
+        if (mt + 2 < NT) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag<KP>(W, mt + 2, kb, m, q); c1[kb] = nd_wfrag<KP>(W, mt + 3, kb, m, q); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sink(mt, a0, a1);
+    }
+}
+// dgrad layer: NT in-feature tiles (two per step), KB k-blocks over the image's rows
+template <int KP, int KB, int NT, typename F>
+__device__ __forceinline__ void nd_layer_T(const float* W, const Op (&in)[KB], int lane, F&& sink) {
+    if constexpr (NT == 1) {
+        f32x4 a0 = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) a0 = VPC_MFMA_BF(nd_wfrag_T<KP>(W, 0, kb, lane), in[kb], a0);
+        sink(0, a0, a0);
+    } else {
+        Op c0[KB], c1[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag_T<KP>(W, 0, kb, lane); c1[kb] = nd_wfrag_T<KP>(W, 1, kb, lane); }
+#pragma unroll
+        for (int mt = 0; mt < NT; mt += 2) {
+            f32x4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) { a0 = VPC_MFMA_BF(c0[kb], in[kb], a0); a1 = VPC_MFMA_BF(c1[kb], in[kb], a1); }
+            if (mt + 2 < NT) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag_T<KP>(W, mt + 2, kb, lane); c1[kb] = nd_wfrag_T<KP>(W, mt + 3, kb, lane); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sink(mt, a0, a1);
+        }
+    }
+}
+// staging: a packed operand (tiles 2 kb, 2 kb + 1 of the lane's row) into slots slot0 + 2 kb (+ 1)
+template <bool BOTH = true>
+__device__ __forceinline__ void nd_st_op(float* st, int row, int slot0, int kb, int q, Op op) {
+    const u32x4 h = __builtin_bit_cast(u32x4, op);
+    const int o0 = bf_stage_off<ND_FT>(row, slot0 + 2 * kb, q);
+    *reinterpret_cast<u32x2*>(st + o0) = u32x2{h[0], h[1]};
+    if (BOTH) *reinterpret_cast<u32x2*>(st + o0 + 64) = u32x2{h[2], h[3]};
+}
+__device__ __forceinline__ Op nd_st_frag(const float* st, int slot, int kb, int lane) {
+    const int g = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
+    const int off = bf_stage_off<ND_FT>(32 * kb + 4 * g + rr, slot, pp);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * ND_FT);
+    const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    return __builtin_bit_cast(Op, h);
+}
+__device__ __forceinline__ f32x4 elu4(f32x4 v) {  // ELU(alpha = 1), hardware exp as the GEMM epilogue (vpc_gemm.hip)
+    return f32x4{v[0] > 0.f ? v[0] : __expf(v[0]) - 1.f, v[1] > 0.f ? v[1] : __expf(v[1]) - 1.f,
+                 v[2] > 0.f ? v[2] : __expf(v[2]) - 1.f, v[3] > 0.f ? v[3] : __expf(v[3]) - 1.f};
+}
+// dy * ELU'(pre) from the PACKED (bf16-rounded) activation h = ELU(pre): 1 where h > 0, else h + 1  (the rounding point the
+// emulating oracle mirrors: notmiwae_oracle.NMTorchPort(elu_gate_rounded=True))
+__device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
+    const u32x4 h = __builtin_bit_cast(u32x4, act);
+    const uint32_t w0 = second ? h[2] : h[0], w1 = second ? h[3] : h[1];
+    const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xffff0000u);
+    const float a2 = __uint_as_float(w1 << 16), a3 = __uint_as_float(w1 & 0xffff0000u);
+    return f32x4{a0 > 0.f ? dy[0] : dy[0] * (a0 + 1.f), a1 > 0.f ? dy[1] : dy[1] * (a1 + 1.f),
+                 a2 > 0.f ? dy[2] : dy[2] * (a2 + 1.f), a3 > 0.f ? dy[3] : dy[3] * (a3 + 1.f)};
+}
+
+#ifdef VPC_ABLATE
+#define ND_BARRIER() do { if (!(a.dbg & 2)) lds_barrier(); } while (0)
+#else
+#define ND_BARRIER() lds_barrier()
+#endif
+
+template <int DT>
+__global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* W1 = lds + NdImg::oW1;
+    const float* W2 = lds + NdImg::oW2;
+    const float* Wx = lds + NdImg::oWx;
+    const float* b1 = lds + NdImg::ob1;
+    const float* b2 = lds + NdImg::ob2;
+    const float* bx = lds + NdImg::obx;
+    const float* Bm = lds + NdImg::oBm;
+    float* SP = lds + NdImg::oSP;
+    float* SG = lds + NdImg::oSG;
+    float* st = lds + NdImg::lds_total;
+    float* lwbuf = st + ND_ST_DW;
+    double* red = reinterpret_cast<double*>(lwbuf + ND_ROWS);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int K = a.K, L = a.L, d = a.d;
+    constexpr int YT = 2 * DT;  // head tiles: xm 0 .. DT - 1, xl DT .. 2 DT - 1
+
+    load_image<27>(lds, a.img, NdImg::total);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const float wv = lds[NdImg::oWm + threadIdx.x];
+        const float e = expf(-fabsf(wv));
+        SP[threadIdx.x] = wv > 20.f ? wv : log1pf(expf(wv));
+        SG[threadIdx.x] = wv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    }
+    __syncthreads();
+
+    // the lane's row inside a tile: replica k of tile-local data row bl
+    const int r = 16 * w + c;
+    const int bl = r / K, k = r - bl * K;
+    const bool rvalid = r < a.nb * K;
+    const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's l_w; their weights are zero)
+
+    f32x4 accx[4][8], accbx[4], acc2[2][8], accb2[2], acc1[2], accb1[2], accwb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accbx[i] = zero4(); accwb[i] = zero4();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accx[i][j] = zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb2[i] = zero4(); acc1[i] = zero4(); accb1[i] = zero4();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc2[i][j] = zero4();
+    }
+    float S[ND_NSTAT] = {0.f, 0.f, 0.f, 0.f, 0.f};  // lse_q (+ KL_q), lse_p (+ KL_p), sum_k RE_e, sum_l kl_el, sum_k RE_q
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const Op ones = __builtin_bit_cast(Op, ones_u);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int cc = c, qq = q;
+        launder(cc, qq);
+        const int pass = tile / a.tiles_per_pass;
+        const bool qpass = pass == 0;
+        const int b0 = (tile - pass * a.tiles_per_pass) * a.nb;
+        const int b = b0 + bl;
+        const bool valid = rvalid && b < a.B;
+        const int bc = valid ? b : (b0 < a.B ? b0 : 0);     // clamped data row (loads of padding rows stay in range)
+        const long R = (long)pass * a.B + bc;               // row of heads / dht
+        const long mrow = R * K + (valid ? k : 0);          // decoder row (eps)
+        // ---------------- reparameterisation (VAE.py:2385-2389): z = mean + eps * exp(logvar / 2)
+        f32x4 z, ehs;  // ehs = eps * exp(logvar / 2) / 2: d z / d logvar
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = 4 * qq + j;
+            const bool lok = l < L;
+            const float mu = lok ? a.heads[R * a.ldh + l] : 0.f;
+            const float lv = lok ? a.heads[R * a.ldh + L + l] : 0.f;
+            const float e = lok ? a.eps[mrow * L + l] : 0.f;
+            const float sd = __expf(0.5f * lv);
+            z[j] = lok ? mu + e * sd : 0.f;
+            ehs[j] = 0.5f * e * sd;
+        }
+        const Op zb = nd_pack2(z, zero4());
+        // ---------------- decoder forward
+        Op g1b[4], g2b[4];
+        {
+            const Op zin[1] = {zb};
+            nd_layer_fwd<32, 1, ND_HT>(W1, zin, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
+                const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq));
+                const f32x4 h1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 16 + 4 * qq));
+                g1b[mt >> 1] = nd_pack2(h0, h1);
+            });
+            launder(cc, qq);
+            nd_layer_fwd<128, 4, ND_HT>(W2, g1b, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
+                const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 4 * qq));
+                const f32x4 h1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 16 + 4 * qq));
+                g2b[mt >> 1] = nd_pack2(h0, h1);
+            });
+        }
+        launder(cc, qq);
+        VPC_CUT();
+        f32x4 Y[YT];  // xm = sigmoid(.), xl = hardtanh(., -10, 0)   (VAE.py:2393-2396)
+        nd_layer_fwd<128, 4, YT>(Wx, g2b, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = mt + h;
+                const f32x4 pre = (h ? a1 : a0) + *reinterpret_cast<const f32x4*>(bx + 16 * t + 4 * qq);
+                if (t < DT) {
+                    Y[t] = f32x4{fast_sigmoid(pre[0]), fast_sigmoid(pre[1]), fast_sigmoid(pre[2]), fast_sigmoid(pre[3])};
+                } else {
+                    Y[t] = f32x4{fminf(fmaxf(pre[0], -10.f), 0.f), fminf(fmaxf(pre[1], -10.f), 0.f),
+                                 fminf(fmaxf(pre[2], -10.f), 0.f), fminf(fmaxf(pre[3], -10.f), 0.f)};
+                }
+            }
+        });
+        launder(cc, qq);
+        VPC_CUT();
+        // ---------------- bound terms of the lane's row, pass 1: sums over the features (VAE.py:2405-2440)
+        const float* xrow = a.x + (long)bc * d + 4 * qq;
+        const float* mrowp = a.m + (long)bc * d + 4 * qq;
+        const float* mprow = a.mp + (long)bc * d + 4 * qq;
+        float sA = 0.f, sE = 0.f, sN = 0.f;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 16 * t);
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(mrowp + 16 * t);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(mprow + 16 * t);
+            const f32x4 sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xm = Y[t][j], xl = Y[DT + t][j];
+                const float rr = xv[j] - xm, riv = rr * __expf(-xl);
+                const float el = 0.5f * xl + 0.5f * rr * riv;
+                if (qpass) {
+                    sA += mv[j] * el;
+                    sE += mv[j] * (1.f - pv[j]) * el;
+                    const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
+                    const float lg = -sp[j] * (mixv - bj[j]);
+                    sN += fmaxf(lg, 0.f) - lg * mv[j] + __logf(1.f + __expf(-fabsf(lg)));
+                } else {
+                    sA += pv[j] * el;
+                }
+            }
+        }
+        sA += __shfl_xor(sA, 16, 64); sA += __shfl_xor(sA, 32, 64);
+        if (qpass) {
+            sE += __shfl_xor(sE, 16, 64); sE += __shfl_xor(sE, 32, 64);
+            sN += __shfl_xor(sN, 16, 64); sN += __shfl_xor(sN, 32, 64);
+        }
+        const float RE = sA + a.cd;
+        const float lw = RE + sN;  // (the analytic KL of the data row is the same for its K replicas: it cancels in the softmax)
+        if (qq == 0) lwbuf[r] = lw;
+        ND_BARRIER();  // B1 (also: every wave is past the previous tile's dz exchange)
+        float wgt;     // softmax weight of the replica x the gradient weight of its pass
+        {
+            float mx = -INFINITY;
+            for (int kk = 0; kk < K; ++kk) mx = fmaxf(mx, lwbuf[blc * K + kk]);
+            float s = 0.f;
+            for (int kk = 0; kk < K; ++kk) s += __expf(lwbuf[blc * K + kk] - mx);
+            const float lse = mx + __logf(s);
+            wgt = valid ? (qpass ? a.oq : a.op) * __expf(lw - lse) : 0.f;
+            if (valid && qq == 0) {
+                if (k == 0) S[qpass ? 0 : 1] += lse;
+                if (qpass) { S[2] += sE + a.cd; S[4] += RE; }
+            }
+        }
+        // ---------------- pass 2: gradients w.r.t. the head PRE-activations (through Sigmoid / Hardtanh), packed as they are made
+        Op Gb[DT], E1b[DT / 2], E2b[DT / 2];
+        {
+            f32x4 gm_prev = zero4(), gl_prev = zero4(), e1_prev = zero4(), e2_prev = zero4();
+            const float oe = valid ? a.oe : 0.f;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 16 * t);
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mrowp + 16 * t);
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(mprow + 16 * t);
+                const f32x4 sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
+                const f32x4 bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
+                f32x4 gm, gl, e1 = zero4(), e2 = zero4();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xm = Y[t][j], xl = Y[DT + t][j];
+                    const float rr = xv[j] - xm, riv = rr * __expf(-xl);
+                    const float h2 = 0.5f - 0.5f * rr * riv;  // d / d xl of the element NLL
+                    float gxm, gxl;
+                    if (qpass) {
+                        const float ee = oe * mv[j] * (1.f - pv[j]);
+                        const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
+                        const float lg = -sp[j] * (mixv - bj[j]);
+                        const float el2 = __expf(-fabsf(lg)), rc = __builtin_amdgcn_rcpf(1.f + el2);
+                        const float dn = (lg >= 0.f ? rc : el2 * rc) - mv[j];
+                        gxm = wgt * (-mv[j] * riv - dn * sp[j] * (1.f - mv[j])) - ee * riv;
+                        gxl = (wgt * mv[j] + ee) * h2;
+                        e1[j] = wgt * dn;
+                        e2[j] = e1[j] * (mixv - bj[j]);
+                    } else {
+                        gxm = -wgt * pv[j] * riv;
+                        gxl = wgt * pv[j] * h2;
+                    }
+                    gm[j] = gxm * (xm * (1.f - xm));
+                    gl[j] = (xl > -10.f && xl < 0.f) ? gxl : 0.f;
+                }
+                if (t & 1) {
+                    Gb[t >> 1] = nd_pack2(gm_prev, gm);
+                    Gb[DT / 2 + (t >> 1)] = nd_pack2(gl_prev, gl);
+                    E1b[t >> 1] = nd_pack2(e1_prev, e1);
+                    E2b[t >> 1] = nd_pack2(e2_prev, e2);
+                }
+                gm_prev = gm; gl_prev = gl; e1_prev = e1; e2_prev = e2;
+            }
+        }
+        launder(cc, qq);
+        VPC_CUT();
+        // ---------------- R1a: dWx rows of the mean head, their bias, db of the missingness model
+        const int fl = 16 * qq + cc;
+#pragma unroll
+        for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[kb]);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) nd_st_op(st, r, 8, kb, qq, g2b[kb]);
+        if (qpass) {
+#pragma unroll
+            for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E1b[kb]);
+        }
+        ND_BARRIER();  // B2
+        auto round_x = [&](int half) {  // owner: wave w -> head tiles w and w + 4 of this half (DT = 8: both exist)
+#pragma unroll
+            for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+                Op fb[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) fb[nt] = nd_st_frag(st, 8 + nt, kb, fl);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (w + 4 * i >= DT) continue;
+                    const Op fa = nd_st_frag(st, w + 4 * i, kb, fl);
+                    const int ai = 2 * half + i;
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) accx[ai][nt] = VPC_MFMA_BF(fa, fb[nt], accx[ai][nt]);
+                    accbx[ai] = VPC_MFMA_BF(fa, ones, accbx[ai]);
+                }
+                if (qpass && 2 * w < DT) {  // column sums of e1 (half 0) / e2 (half 1): tiles 2 w, 2 w + 1
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const Op fe = nd_st_frag(st, 16 + 2 * w + i, kb, fl);
+                        accwb[2 * half + i] = VPC_MFMA_BF(fe, ones, accwb[2 * half + i]);
+                    }
+                }
+            }
+        };
+        round_x(0);
+        ND_BARRIER();  // B3
+        // ---------------- R1b: the log-variance head (g2 stays in slots 8-15)
+#pragma unroll
+        for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[DT / 2 + kb]);
+        if (qpass) {
+#pragma unroll
+            for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E2b[kb]);
+        }
+        ND_BARRIER();  // B4
+        round_x(1);
+        launder(cc, qq);
+        VPC_CUT();
+        // ---------------- dg2 = ELU'(g2) * (Wx^T G)
+        Op dg2b[4];
+        nd_layer_T<128, DT, ND_HT>(Wx, Gb, fl, [&](int mt, f32x4 a0, f32x4 a1) {
+            dg2b[mt >> 1] = nd_pack2(elu_gate(a0, g2b[mt >> 1], 0), elu_gate(a1, g2b[mt >> 1], 1));
+        });
+        launder(cc, qq);
+        VPC_CUT();
+        ND_BARRIER();  // B5: every wave is past the reads of R1b
+        // ---------------- R2: dW2 = dg2^T g1, db2   (owner: wave w -> out tiles 2 w, 2 w + 1)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { nd_st_op(st, r, 0, kb, qq, dg2b[kb]); nd_st_op(st, r, 8, kb, qq, g1b[kb]); }
+        ND_BARRIER();  // B6
+#pragma unroll
+        for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+            Op fb[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) fb[nt] = nd_st_frag(st, 8 + nt, kb, fl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Op fa = nd_st_frag(st, 2 * w + i, kb, fl);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) acc2[i][nt] = VPC_MFMA_BF(fa, fb[nt], acc2[i][nt]);
+                accb2[i] = VPC_MFMA_BF(fa, ones, accb2[i]);
+            }
+        }
+        launder(cc, qq);
+        VPC_CUT();
+        // ---------------- dg1 = ELU'(g1) * (W2^T dg2);  dz = W1^T dg1
+        Op dg1b[4];
+        nd_layer_T<128, 4, ND_HT>(W2, dg2b, fl, [&](int mt, f32x4 a0, f32x4 a1) {
+            dg1b[mt >> 1] = nd_pack2(elu_gate(a0, g1b[mt >> 1], 0), elu_gate(a1, g1b[mt >> 1], 1));
+        });
+        f32x4 dz = zero4();
+        nd_layer_T<32, 4, 1>(W1, dg1b, fl, [&](int, f32x4 a0, f32x4) { dz = a0; });
+        launder(cc, qq);
+        ND_BARRIER();  // B7
+        // ---------------- R3: dW1 = dg1^T z, db1
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) nd_st_op(st, r, 0, kb, qq, dg1b[kb]);
+        nd_st_op<false>(st, r, 8, 0, qq, zb);
+        ND_BARRIER();  // B8
+#pragma unroll
+        for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+            const Op fb = nd_st_frag(st, 8, kb, fl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Op fa = nd_st_frag(st, 2 * w + i, kb, fl);
+                acc1[i] = VPC_MFMA_BF(fa, fb, acc1[i]);
+                accb1[i] = VPC_MFMA_BF(fa, ones, accb1[i]);
+            }
+        }
+        ND_BARRIER();  // B9: the staging area becomes the dz exchange [64 rows][mean 16 | logvar 16]
+        {
+            float* dzx = st;
+            const f32x4 dm = valid ? dz : zero4();
+            const f32x4 dl = valid ? dz * ehs : zero4();
+            *reinterpret_cast<f32x4*>(dzx + r * 32 + 4 * qq) = dm;
+            *reinterpret_cast<f32x4*>(dzx + r * 32 + 16 + 4 * qq) = dl;
+        }
+        ND_BARRIER();  // B10
+        // ---------------- sum over the K replicas (nm_sample_bwd) + the analytic KL terms and their gradients (VAE.py:2441-2452)
+        if ((int)threadIdx.x < 16 * a.nb) {
+            const int ebl = threadIdx.x >> 4, l = threadIdx.x & 15;
+            const int eb = b0 + ebl;
+            if (eb < a.B && l < L) {
+                const float* dzx = st;
+                float sm = 0.f, sl = 0.f;
+                for (int kk = 0; kk < K; ++kk) {
+                    sm += dzx[(ebl * K + kk) * 32 + l];
+                    sl += dzx[(ebl * K + kk) * 32 + 16 + l];
+                }
+                const float* hq = a.heads + (long)eb * a.ldh;
+                const float* hp = a.heads + ((long)a.B + eb) * a.ldh;
+                const float mu_q = hq[l], lv_q = hq[L + l], mu_p = hp[l], lv_p = hp[L + l];
+                const float eq = expf(lv_q), ep = expf(lv_p), ivp = expf(-lv_p), ratio = expf(lv_q - lv_p);
+                const float dm = mu_q - mu_p;
+                float gmu, glv;
+                if (qpass) {
+                    gmu = a.kq * mu_q + a.cr * dm * ivp;
+                    glv = a.kq * 0.5f * (eq - 1.f) + a.cr * 0.5f * (ratio - 1.f);
+                    S[0] += 0.5f * (eq + mu_q * mu_q - 1.f - lv_q);
+                    S[3] += 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p));
+                } else {
+                    gmu = a.kp * mu_p - a.cr * dm * ivp;
+                    glv = a.kp * 0.5f * (ep - 1.f) + a.cr * 0.5f * (1.f - ratio - dm * dm * ivp);
+                    S[1] += 0.5f * (ep + mu_p * mu_p - 1.f - lv_p);
+                }
+                float* o = a.dht + ((long)pass * a.B + eb) * (2 * L);
+                o[l] = gmu + sm;
+                o[L + l] = glv + sl;
+            }
+        }
+    }
+
+    // ---------------- partial block of the workgroup (register-major, coalesced) and its statistics
+    float* part = a.part + (long)blockIdx.x * ND_PART + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(R_X + (8 * i + nt) * 4 + j) * ND_THREADS] = accx[i][nt][j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(R_BX + 4 * i + j) * ND_THREADS] = accbx[i][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(R_2 + (8 * i + nt) * 4 + j) * ND_THREADS] = acc2[i][nt][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            part[(R_B2 + 4 * i + j) * ND_THREADS] = accb2[i][j];
+            part[(R_1 + 4 * i + j) * ND_THREADS] = acc1[i][j];
+            part[(R_B1 + 4 * i + j) * ND_THREADS] = accb1[i][j];
+        }
+    // missingness model: accwb[i] = sum over rows of e1 (i < 2: features 16 (2 w + i) + 4 q + j) / e2 (i >= 2);
+    // db = softplus(W) * sum e1, dW = -sigmoid(W) * sum e2   (VAE.py:2424-2431 through autograd)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = (16 * (2 * w + (i & 1)) + 4 * q + j) & 127;
+            part[(R_WB + 4 * i + j) * ND_THREADS] = (i < 2) ? SP[f] * accwb[i][j] : -SG[f] * accwb[i][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ND_NSTAT; ++i) {
+        const float v = wave_sum_dpp(S[i]);
+        if (lane == 0) red[w * ND_NSTAT + i] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ND_NSTAT)
+        a.stat_part[(long)blockIdx.x * ND_NSTAT + threadIdx.x] =
+            (red[threadIdx.x] + red[ND_NSTAT + threadIdx.x]) + (red[2 * ND_NSTAT + threadIdx.x] + red[3 * ND_NSTAT + threadIdx.x]);
+}
+
+// fixed-order reduction of the partial blocks into the flat gradient (W | b of the missingness model and the decoder segment)
+// + the loss terms (block 0), as nm_finalize_kernel of vpc_nm.hip
+struct NmdFinArgs {
+    const float* part; const double* stat_part; int n_blocks;
+    const int* grad_idx; float* grad; int n;   // grad[i] = sum over blocks of part[block][grad_idx[i]] where grad_idx[i] >= 0
+    int B, K, L; double alpha, inv_B;
+    double* out; float* loss_f32; float* accum; long long* state; long long rng_inc;
+};
+__global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
+    if (blockIdx.x > 0) {
+        const int i = (blockIdx.x - 1) * 256 + threadIdx.x;
+        if (i >= a.n) return;
+        const int gi = a.grad_idx[i];
+        if (gi < 0) return;
+        const float* p = a.part + gi;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int blk = 0;
+        for (; blk + 3 < a.n_blocks; blk += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += p[(long)(blk + u) * ND_PART];
+        }
+        for (; blk < a.n_blocks; ++blk) acc[0] += p[(long)blk * ND_PART];
+        a.grad[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        return;
+    }
+    __shared__ double red[256][ND_NSTAT];
+    double s[ND_NSTAT] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < a.n_blocks; b += 256)
+        for (int i = 0; i < ND_NSTAT; ++i) s[i] += a.stat_part[(long)b * ND_NSTAT + i];
+    for (int i = 0; i < ND_NSTAT; ++i) red[threadIdx.x][i] = s[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int i = 0; i < ND_NSTAT; ++i) red[threadIdx.x][i] += red[threadIdx.x + o][i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double logK = log((double)a.K);
+        const double loss_q = red[0][0] * a.inv_B - logK * (a.B * a.inv_B);
+        const double loss_p = red[0][1] * a.inv_B - logK * (a.B * a.inv_B);
+        const double nll_e = red[0][2] * a.inv_B / a.K;
+        const double kl_reg = red[0][3] * a.inv_B / a.L;
+        a.out[0] = loss_q + a.alpha * (kl_reg - loss_q + loss_p + nll_e);
+        a.out[1] = loss_q; a.out[2] = loss_p; a.out[3] = kl_reg; a.out[4] = nll_e;
+        a.out[5] = red[0][4] * a.inv_B / a.K;
+        a.out[6] = red[0][0]; a.out[7] = red[0][1];
+        if (a.loss_f32) a.loss_f32[0] = (float)a.out[0];
+        if (a.accum) a.accum[0] += (float)a.out[0];
+        if (a.state) { a.state[0] += 1; a.state[1] += a.rng_inc; }
+    }
+}
+
+static inline bool nmdec_shape_ok(int K, int d, int L) { return d == 128 && L >= 1 && L <= 15 && K >= 4 && K <= ND_ROWS; }
+
+}  // namespace vpc
+
+using namespace vpc;
+
+extern "C" {
+
+// 1 when vpc_nmdec_step covers the shape (the regularised model only; obs_dim = 128, latent_dim <= 15, 4 <= K <= 64);
+// VPC_NMDEC=0 in the environment keeps the GEMM chain (A/B runs)
+int vpc_nmdec_applicable(long B, int K, int d, int L) {
+    if (B <= 0 || !nmdec_shape_ok(K, d, L)) return 0;
+    if (const char* e = getenv("VPC_NMDEC")) {
+        if (atoi(e) == 0) return 0;
+    }
+    return 1;
+}
+
+// sizes the caller allocates: the image (floats), one partial block (floats) and the most workgroups a launch uses
+int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks) {
+    if (B <= 0 || !nmdec_shape_ok(K, d, L)) return VPC_ERR_SHAPE;
+    if (img_floats) *img_floats = NdImg::total;
+    if (part_floats) *part_floats = ND_PART;
+    if (max_blocks) {
+        const int nb = ND_ROWS / K;
+        const long tiles = 2 * ((B + nb - 1) / nb);
+        const long cap = num_cus();
+        *max_blocks = (int)(tiles < cap ? tiles : cap);
+    }
+    return VPC_OK;
+}
+
+// index tables over the model's flat parameter buffer [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]
+// (notmiwae.py _flat_order; n = its length):  pack_idx[i] as vpc_step_pack_weights_bf16 reads it (u16 position inside the image,
+// -(dword + 1) for values that stay fp32, INT_MIN = not in the image: the encoder),  grad_idx[i] = position of parameter i's
+// gradient inside a partial block (-1: the encoder's parameters, whose gradients the GEMM chain writes)
+int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n) {
+    if (hid != ND_HID || !nmdec_shape_ok(4, d, L)) return VPC_ERR_SHAPE;
+    if (!pack_idx || !grad_idx) return VPC_ERR_ARG;
+    const int n_enc = hid * d + hid + hid * hid + hid + 2 * L * hid + 2 * L;
+    const int n_dec = hid * L + hid + hid * hid + hid + 2 * d * hid + 2 * d;
+    if (n != 2 * d + n_enc + n_dec) return VPC_ERR_ARG;
+    for (int i = 0; i < n; ++i) { pack_idx[i] = INT_MIN; grad_idx[i] = -1; }
+    // position inside a partial block of accumulator register `reg` of thread (wave w, lane 16 q + c)
+    auto pos = [](int reg, int w, int q, int c) { return reg * ND_THREADS + 64 * w + 16 * q + c; };
+    // missingness model: accwb[i] of wave w: features 16 (2 w + (i & 1)) + 4 q + j; i < 2 -> db, i >= 2 -> dW
+    for (int f = 0; f < d; ++f) {
+        const int t = f >> 4, w = t >> 1, i = t & 1, q = (f >> 2) & 3, j = f & 3;
+        pack_idx[f] = -(NdImg::oWm + f + 1);
+        pack_idx[d + f] = -(NdImg::oBm + f + 1);
+        grad_idx[f] = pos(R_WB + 4 * (2 + i) + j, w, q, 0);
+        grad_idx[d + f] = pos(R_WB + 4 * i + j, w, q, 0);
+    }
+    int o = 2 * d + n_enc;
+    const int oWd1 = o, obd1 = oWd1 + hid * L, oWd2 = obd1 + hid, obd2 = oWd2 + hid * hid, oWx = obd2 + hid,
+              obx = oWx + 2 * d * hid;
+    for (int r = 0; r < hid; ++r) {  // out feature r of the two hidden layers: tile mt = r >> 4 owned by wave mt >> 1
+        const int mt = r >> 4, w = mt >> 1, i = mt & 1, q = (r >> 2) & 3, j = r & 3;
+        for (int f = 0; f < L; ++f) {
+            pack_idx[oWd1 + r * L + f] = 2 * NdImg::oW1 + nd_elem<32>(r, f);
+            grad_idx[oWd1 + r * L + f] = pos(R_1 + 4 * i + j, w, q, f);
+        }
+        pack_idx[obd1 + r] = -(NdImg::ob1 + r + 1);
+        grad_idx[obd1 + r] = pos(R_B1 + 4 * i + j, w, q, 0);
+        for (int f = 0; f < hid; ++f) {
+            pack_idx[oWd2 + r * hid + f] = 2 * NdImg::oW2 + nd_elem<128>(r, f);
+            grad_idx[oWd2 + r * hid + f] = pos(R_2 + (8 * i + (f >> 4)) * 4 + j, w, q, f & 15);
+        }
+        pack_idx[obd2 + r] = -(NdImg::ob2 + r + 1);
+        grad_idx[obd2 + r] = pos(R_B2 + 4 * i + j, w, q, 0);
+    }
+    for (int r = 0; r < 2 * d; ++r) {  // head rows: tile t = r >> 4; half = t / 8, owner wave (t & 7) & 3, slot i = (t & 7) >> 2
+        const int t = r >> 4, half = t >> 3, tt = t & 7, w = tt & 3, i = tt >> 2, ai = 2 * half + i, q = (r >> 2) & 3, j = r & 3;
+        for (int f = 0; f < hid; ++f) {
+            pack_idx[oWx + r * hid + f] = 2 * NdImg::oWx + nd_elem<128>(r, f);
+            grad_idx[oWx + r * hid + f] = pos(R_X + (8 * ai + (f >> 4)) * 4 + j, w, q, f & 15);
+        }
+        pack_idx[obx + r] = -(NdImg::obx + r + 1);
+        grad_idx[obx + r] = pos(R_BX + 4 * ai + j, w, q, 0);
+    }
+    return VPC_OK;
+}
+
+// The fused decoder + loss + decoder backward of one regularised MNAR step (two launches: the tile kernel and the fixed-order
+// reduction of its partial blocks).  heads [2 B][ldh] = the encoder's (mean | logvar) rows of the q pass, then of the p pass;
+// eps [2 B K][L]; dht [2 B][2 L] receives the gradient w.r.t. heads (K-fold sum of dz + the analytic KL gradients);
+// grad (the model's flat gradient buffer, n entries) receives the entries grad_idx names; out8 / loss_f32 / accum / state as
+// vpc_nm_loss.  part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (vpc_nmdec_layout).
+int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
+                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, float* grad, int n,
+                   double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
+                   int K, int d, int L, double alpha, void* stream) {
+    if (!img || !x || !mask || !mask_p || !heads || !eps || !dht || !part || !stat_part || !grad_idx || !grad || !out8)
+        return VPC_ERR_ARG;
+    if (B <= 0 || B_global < B || ldh < 2 * L || B * (long)K > 0x3fffff00L) return VPC_ERR_ARG;
+    if (!nmdec_shape_ok(K, d, L)) return VPC_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(mask_p) |
+         reinterpret_cast<uintptr_t>(img)) & 15)
+        return VPC_ERR_ARG;
+    NmdArgs a{};
+    a.img = img; a.x = x; a.m = mask; a.mp = mask_p; a.heads = heads; a.ldh = ldh; a.eps = eps; a.dht = dht; a.part = part;
+    a.stat_part = stat_part; a.B = (int)B; a.K = K; a.d = d; a.L = L;
+    a.nb = ND_ROWS / K;
+    a.tiles_per_pass = (int)((B + a.nb - 1) / a.nb);
+    a.ntiles = 2 * a.tiles_per_pass;
+    const double Bg = (double)B_global;
+    a.oq = (float)((1.0 - alpha) / Bg); a.op = (float)(alpha / Bg); a.oe = (float)(alpha / (Bg * K));
+    a.cr = (float)(alpha / (Bg * L)); a.kq = a.oq; a.kp = a.op;
+    a.cd = 0.91893853320467274f * (float)d;
+#ifdef VPC_ABLATE
+    if (const char* e = getenv("VPC_DEBUG")) a.dbg = atoi(e);
+#endif
+    const int cap = num_cus();
+    const int blocks = a.ntiles < cap ? a.ntiles : cap;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nmdec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ND_LDS) !=
+            hipSuccess)
+            return VPC_ERR_HIP;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((nmdec_kernel<8>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
+    if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
+    NmdFinArgs f{};
+    f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.grad_idx = grad_idx; f.grad = grad; f.n = n;
+    f.B = (int)B; f.K = K; f.L = L; f.alpha = alpha; f.inv_B = 1.0 / Bg;
+    f.out = out8; f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
+    hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(1 + (n + 255) / 256), dim3(256), 0, st, f);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+}  // extern "C"

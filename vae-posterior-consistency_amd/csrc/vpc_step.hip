@@ -25,6 +25,7 @@
 #include "vpc_device.h"
 #include "vpc_bf16.h"
 #include "vpc_dec_args.h"
+#include <climits>
 #include <cstring>
 #include <type_traits>
 
@@ -1100,6 +1101,7 @@ __global__ void pack_bf16c_kernel(const float* __restrict__ flat, const int* __r
     if (i >= n) return;
     const float v = flat[i];
     const int e = idx[i];
+    if (e == INT_MIN) return;  // a parameter that is not part of this image (vpc_nmdec_build_indices: the encoder's)
     if (e < 0) { img[-(e + 1)] = v; return; }
     reinterpret_cast<unsigned short*>(img)[e] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
 }

@@ -112,6 +112,29 @@ def nm_loss(x, mask, mask_p, xm_q, xl_q, ldq, xm_p, xl_p, ldp, hq, hp, W, b, eps
           "vpc_nm_loss")
 
 
+def nmdec_applicable(B, K, d, Ld):
+    return bool(lib().vpc_nmdec_applicable(int(B), int(K), int(d), int(Ld)))
+
+
+def nmdec_tables(model, device):
+    """(pack_idx, grad_idx) on the device + image size in floats for the layer-fused decoder kernel (csrc/vpc_nmdec.hip)."""
+    import numpy as np
+    d, Ld = model.obs_dim, model.latent_dim
+    n = 2 * d + model._n_enc + model._n_dec
+    pidx, gidx = np.empty(n, np.int32), np.empty(n, np.int32)
+    check(lib().vpc_nmdec_build_indices(d, Ld, HID, pidx.ctypes.data_as(L.P), gidx.ctypes.data_as(L.P), n),
+          "vpc_nmdec_build_indices")
+    return torch.from_numpy(pidx).to(device), torch.from_numpy(gidx).to(device)
+
+
+def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, grad, out8, loss_f32, accum, B, B_global, K, d,
+               Ld, alpha, state=None, rng_inc=0):
+    check(lib().vpc_nmdec_step(ptr(img), ptr(x), ptr(mask), ptr(mask_p), ptr(heads), 2 * Ld, ptr(eps), ptr(dht),
+                               ptr(part), ptr(stat), ptr(gidx), ptr(grad), grad.numel(), ptr(out8), ptr(loss_f32),
+                               ptr(accum), ptr(state), int(rng_inc), B, B_global, K, d, Ld, float(alpha), stream_ptr()),
+          "vpc_nmdec_step")
+
+
 def _f32c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
@@ -573,13 +596,17 @@ class NMTrainer:
         self.xin, self.mask_p = e(R, d), e(B, d)
         self.h1, self.h2, self.heads = e(R, HID), e(R, HID), e(R, 2 * Ld)
         self.eps = e(2, B, K, Ld)  # reg: eps_q, eps_p; vanilla: eps (sampling), eps_kl (MC KL)
-        self.z, self.g1, self.g2, self.Y = e(M, Ld), e(M, HID), e(M, HID), e(M, 2 * d)
-        self.G, self.gheads, self.dht = e(M, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
-        self.dg2, self.dg1, self.dz = e(M, HID), e(M, HID), e(M, Ld)
+        # layer-fused decoder (plain bf16, regularised model, obs_dim 128): nothing of B * K rows is materialised
+        self.use_nmdec = bool(self.reg and self.prec == 2 and nmdec_applicable(B, K, d, Ld))
+        Mg = 0 if self.use_nmdec else M  # rows of the GEMM chain's decoder-side workspaces
+        self.z, self.g1, self.g2, self.Y = e(Mg, Ld), e(Mg, HID), e(Mg, HID), e(Mg, 2 * d)
+        self.G, self.gheads, self.dht = e(Mg, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
+        self.dg2, self.dg1, self.dz = e(Mg, HID), e(Mg, HID), e(Mg, Ld)
         self.dh2, self.dh1 = e(R, HID), e(R, HID)
         # per-layer partial buffers of the six weight gradients (summed by ONE launch at the end of the backward pass)
         self.wg_shapes = [(M, 2 * d, HID), (M, HID, HID), (M, HID, Ld), (R, 2 * Ld, HID), (R, HID, HID), (R, HID, d)]
-        sizes = [int(lib().vpc_linear_wgrad_scratch(*sh)) for sh in self.wg_shapes]
+        sizes = [0 if (self.use_nmdec and i < 3) else int(lib().vpc_linear_wgrad_scratch(*sh))
+                 for i, sh in enumerate(self.wg_shapes)]
         buf = e(sum(sizes))
         self._wg_cache = {}
         self.wg_scratch, o = [], 0
@@ -588,6 +615,14 @@ class NMTrainer:
             o += n
         nbytes = int(lib().vpc_nm_loss_scratch(B, d))
         self.scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+        if self.use_nmdec:  # image, partial blocks, index tables
+            nimg, npart, nblk = C.c_int(), C.c_long(), C.c_int()
+            check(lib().vpc_nmdec_layout(B, K, d, Ld, C.byref(nimg), C.byref(npart), C.byref(nblk)), "vpc_nmdec_layout")
+            if getattr(self, "_nd_tables", None) is None:
+                self._nd_tables = nmdec_tables(m, dev)
+                self.nd_img = torch.zeros(nimg.value, device=dev)
+            self.nd_part = e(nblk.value * npart.value)
+            self.nd_stat = torch.empty(nblk.value * 5, dtype=torch.float64, device=dev)
         self._B = B
 
     def _t(self, name, fn, *a, **kw):
@@ -645,19 +680,6 @@ class NMTrainer:
         t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU, precision=self.prec)
         t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU, precision=self.prec)
         t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE, precision=self.prec)
-        t("sample", nm_sample, self.heads, self.eps if reg else self.eps[0], self.z, R, K, Ld)
-        t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU, precision=self.prec)
-        t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU, precision=self.prec)
-        t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d, precision=self.prec)
-        # ---- loss + output-side gradients
-        Y, G = self.Y, self.G
-        t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
-          self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
-          G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
-          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss,
-          self.accum if self.world_size == 1 else None,  # data parallel: the epoch total takes the ALL-REDUCED loss (below)
-          B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
-        # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
         g = self.g
         # weight gradients: partials per layer, all summed by one launch after the last one (6 reduction launches less;
         # the timer mode keeps the per-layer form so that every entry brackets a complete gradient)
@@ -671,14 +693,17 @@ class NMTrainer:
             linear_wgrad(dy, xx, None, None, Mi, Ni, Ki, precision=self.prec, scratch=self.wg_scratch[i])
             pend.append((self.wg_scratch[i], Mi, Ni, Ki, dw, db, False))
 
-        wgrad("dec_wgrad3", 0, G, self.g2, g["Wx"], g["bx"])
-        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, precision=self.prec)
-        wgrad("dec_wgrad2", 1, self.dg2, self.g1, g["Wd2"], g["bd2"])
-        t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU, precision=self.prec)
-        wgrad("dec_wgrad1", 2, self.dg1, self.z, g["Wd1"], g["bd1"])
-        t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld, precision=self.prec)
-        t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
-          K, Ld)
+        if self.use_nmdec:
+            # K-fold rsample, decoder, loss, decoder backward and the K-fold sum of dz in ONE kernel (csrc/vpc_nmdec.hip): the
+            # decoder / missingness-model gradients land in self.grad, d loss / d heads in self.dht
+            pidx, gidx = self._nd_tables
+            from .ops import step_pack_weights_bf16
+            t("pack", step_pack_weights_bf16, m._flat, pidx, self.nd_img)
+            t("dec_fused", nmdec_step, self.nd_img, xf, mf, mp, self.heads, self.eps, self.dht, self.nd_part, self.nd_stat,
+              gidx, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
+              _state, rng_inc)
+        else:
+            self._step_decoder_gemms(xf, mf, mp, B, Bg, alpha, _state, rng_inc, t, v, wgrad)
         wgrad("enc_bwd", 3, self.dht, self.h2, g["Wh"], g["bh"])
         t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU, precision=self.prec)
         wgrad("enc_bwd", 4, self.dh2, self.h1, g["We2"], g["be2"])
@@ -697,6 +722,35 @@ class NMTrainer:
         t("adam", adam_step, m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
           self.betas[0], self.betas[1], self.eps_adam, None, None, None if _state is None else _state[0:1],
           loss_in=self.loss if self.world_size > 1 else None, accum=self.accum if self.world_size > 1 else None)
+
+    def _step_decoder_gemms(self, xf, mf, mp, B, Bg, alpha, _state, rng_inc, t, v, wgrad):
+        """Decoder forward, loss and decoder backward as the GEMM chain (every precision, both model classes)."""
+        m, reg = self.model, self.reg
+        d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
+        P = 2 if reg else 1
+        R, M, BK = P * B, P * B * K, B * K
+        t("sample", nm_sample, self.heads, self.eps if reg else self.eps[0], self.z, R, K, Ld)
+        t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU, precision=self.prec)
+        t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU, precision=self.prec)
+        t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d, precision=self.prec)
+        # ---- loss + output-side gradients
+        Y, G = self.Y, self.G
+        t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
+          self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
+          G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
+          self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss,
+          self.accum if self.world_size == 1 else None,  # data parallel: the epoch total takes the ALL-REDUCED loss (below)
+          B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
+        # ---- backward (G already holds the head pre-activation gradients: no gate pass over Y)
+        g = self.g
+        wgrad("dec_wgrad3", 0, G, self.g2, g["Wx"], g["bx"])
+        t("dec_dgrad3", linear_dgrad, G, v["Wx"], self.dg2, M, 2 * d, HID, x_out=self.g2, act_prev=ACT_ELU, precision=self.prec)
+        wgrad("dec_wgrad2", 1, self.dg2, self.g1, g["Wd2"], g["bd2"])
+        t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU, precision=self.prec)
+        wgrad("dec_wgrad1", 2, self.dg1, self.z, g["Wd1"], g["bd1"])
+        t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld, precision=self.prec)
+        t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
+          K, Ld)
 
     def step_graph(self, x, mask, *, alpha=1.0, p_missingness=30):
         """The same step replayed from a captured HIP graph (torch.cuda.CUDAGraph): ONE host call instead of ~30
