@@ -29,6 +29,7 @@
 #include "vpc_dec_args.h"
 #include <climits>
 #include <cstring>
+#include <type_traits>
 
 namespace vpc {
 
@@ -47,6 +48,11 @@ constexpr int ND_WAVES = 4, ND_THREADS = 256, ND_ROWS = 64, ND_HID = 128, ND_HT 
 constexpr int ND_FT = 24;                                  // staging slots per row
 constexpr int ND_ST_DW = (ND_ROWS / 8) * ND_FT * 64;       // 12 288 dwords
 constexpr int ND_NSTAT = 5;
+// a tile's inputs, staged once per tile by the whole workgroup in the (then idle) staging area: x | mask | mask_p rows of its data
+// rows, the eps rows of its replicas (padded to 16), the (mean | logvar) rows of its data rows (16 | 16)
+constexpr int ND_XIN = 0, ND_EPS = ND_XIN + 16 * 3 * 128, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + 16 * 32;
+static_assert(ND_IN_DW <= ND_ST_DW, "tile inputs alias the staging area");
+constexpr int ND_LWB = 128;  // l_w exchange: data-row groups of (K + 3) & ~3 floats, unused entries stay -inf
 // dword offsets inside the image (global and LDS): bf16 layers, fp32 biases, raw W / b of the missingness model; LDS only: their
 // softplus / sigmoid
 struct NdImg {
@@ -54,7 +60,7 @@ struct NdImg {
                          obx = ob2 + ND_HID, oWm = obx + 256, oBm = oWm + 128, total = oBm + 128, oSP = total, oSG = oSP + 128,
                          lds_total = oSG + 128;
 };
-constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_ROWS + 2 * ND_WAVES * ND_NSTAT) * 4;
+constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_LWB + 2 * ND_WAVES * ND_NSTAT) * 4;
 static_assert(ND_LDS <= 163840, "LDS budget");
 // partial block: [248 accumulator registers][256 threads]
 constexpr int ND_REGS = 248, ND_PART = ND_REGS * ND_THREADS;
@@ -115,7 +121,8 @@ __device__ __forceinline__ void nd_layer_fwd(const float* W, const Op (&in)[KB],
         sink(mt, a0, a1);
     }
 }
-// dgrad layer: NT in-feature tiles (two per step), KB k-blocks over the image's rows
+// dgrad layer: NT in-feature tiles (two per step; one per step when the fragments of two tiles would be 64 registers), KB k-blocks
+// over the image's rows
 template <int KP, int KB, int NT, typename F>
 __device__ __forceinline__ void nd_layer_T(const float* W, const Op (&in)[KB], int lane, F&& sink) {
     if constexpr (NT == 1) {
@@ -123,6 +130,30 @@ __device__ __forceinline__ void nd_layer_T(const float* W, const Op (&in)[KB], i
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a0 = VPC_MFMA_BF(nd_wfrag_T<KP>(W, 0, kb, lane), in[kb], a0);
         sink(0, a0, a0);
+    } else if constexpr (KB > 4) {
+        // two accumulator chains over the k-blocks of ONE tile pair, fragments fetched in two halves of KB / 2 blocks
+        constexpr int HB = KB / 2;
+#pragma unroll
+        for (int mt = 0; mt < NT; mt += 2) {
+            f32x4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Op c0[HB], c1[HB];
+#pragma unroll
+                for (int kb = 0; kb < HB; ++kb) {
+                    c0[kb] = nd_wfrag_T<KP>(W, mt, h * HB + kb, lane);
+                    c1[kb] = nd_wfrag_T<KP>(W, mt + 1, h * HB + kb, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = 0; kb < HB; ++kb) {
+                    a0 = VPC_MFMA_BF(c0[kb], in[h * HB + kb], a0);
+                    a1 = VPC_MFMA_BF(c1[kb], in[h * HB + kb], a1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sink(mt, a0, a1);
+        }
     } else {
         Op c0[KB], c1[KB];
 #pragma unroll
@@ -139,6 +170,29 @@ __device__ __forceinline__ void nd_layer_T(const float* W, const Op (&in)[KB], i
             __builtin_amdgcn_sched_barrier(0);
             sink(mt, a0, a1);
         }
+    }
+}
+// the two heads, tile by tile: out tiles t (mean head) and DT + t (log-variance head) as two MFMA chains; pre(t) runs BEFORE the
+// tile's MFMAs (LDS reads issued there arrive under them), sink(t, mean tile, logvar tile) after; the next tile's weight
+// fragments are requested behind the MFMAs
+template <int DT, typename P, typename F>
+__device__ __forceinline__ void nd_heads(const float* W, const Op (&in)[4], int m, int q, P&& pre, F&& sink) {
+    Op c0[4], c1[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) { c0[kb] = nd_wfrag<128>(W, 0, kb, m, q); c1[kb] = nd_wfrag<128>(W, DT, kb, m, q); }
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        pre(t);
+        f32x4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { a0 = VPC_MFMA_BF(c0[kb], in[kb], a0); a1 = VPC_MFMA_BF(c1[kb], in[kb], a1); }
+        if (t + 1 < DT) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { c0[kb] = nd_wfrag<128>(W, t + 1, kb, m, q); c1[kb] = nd_wfrag<128>(W, DT + t + 1, kb, m, q); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sink(t, a0, a1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // staging: a packed operand (tiles 2 kb, 2 kb + 1 of the lane's row) into slots slot0 + 2 kb (+ 1)
@@ -174,13 +228,19 @@ __device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
 
 #ifdef VPC_ABLATE
 #define ND_BARRIER() do { if (!(a.dbg & 2)) lds_barrier(); } while (0)
+#define NSTP(i) VPC_STAMP(i)
 #else
 #define ND_BARRIER() lds_barrier()
+#define NSTP(i) do {} while (0)
 #endif
 
 template <int DT>
 __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VPC_ABLATE
+    unsigned long long T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     const float* W1 = lds + NdImg::oW1;
     const float* W2 = lds + NdImg::oW2;
     const float* Wx = lds + NdImg::oWx;
@@ -192,13 +252,14 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     float* SG = lds + NdImg::oSG;
     float* st = lds + NdImg::lds_total;
     float* lwbuf = st + ND_ST_DW;
-    double* red = reinterpret_cast<double*>(lwbuf + ND_ROWS);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    double* red = reinterpret_cast<double*>(lwbuf + ND_LWB);
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, q = lane >> 4;
     const int K = a.K, L = a.L, d = a.d;
     constexpr int YT = 2 * DT;  // head tiles: xm 0 .. DT - 1, xl DT .. 2 DT - 1
 
     load_image<27>(lds, a.img, NdImg::total);
     __syncthreads();
+    if (threadIdx.x < ND_LWB) lwbuf[threadIdx.x] = -INFINITY;
     if (threadIdx.x < 128) {
         const float wv = lds[NdImg::oWm + threadIdx.x];
         const float e = expf(-fabsf(wv));
@@ -211,7 +272,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     const int r = 16 * w + c;
     const int bl = r / K, k = r - bl * K;
     const bool rvalid = r < a.nb * K;
-    const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's l_w; their weights are zero)
+    const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's inputs and l_w; their weights are zero)
+    const int KP4 = (K + 3) & ~3;
 
     f32x4 accx[4][8], accbx[4], acc2[2][8], accb2[2], acc1[2], accb1[2], accwb[4];
 #pragma unroll
@@ -230,6 +292,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const Op ones = __builtin_bit_cast(Op, ones_u);
 
+    NSTP(0);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
         launder(cc, qq);
@@ -238,23 +301,50 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         const int b0 = (tile - pass * a.tiles_per_pass) * a.nb;
         const int b = b0 + bl;
         const bool valid = rvalid && b < a.B;
-        const int bc = valid ? b : (b0 < a.B ? b0 : 0);     // clamped data row (loads of padding rows stay in range)
-        const long R = (long)pass * a.B + bc;               // row of heads / dht
-        const long mrow = R * K + (valid ? k : 0);          // decoder row (eps)
-        // ---------------- reparameterisation (VAE.py:2385-2389): z = mean + eps * exp(logvar / 2)
-        f32x4 z, ehs;  // ehs = eps * exp(logvar / 2) / 2: d z / d logvar
+        // ---------------- the tile's inputs -> LDS, once per tile (every replica of a data row reads the same x / masks / statistics)
+        {
+            const long m0 = ((long)pass * a.B + b0) * K;  // first decoder row (eps row) of the tile
+            for (int i = threadIdx.x; i < a.nb * 96; i += ND_THREADS) {
+                const int row = i / 96, rem = i - 96 * row, arr = rem >> 5, c4 = rem & 31;
+                const int br = b0 + row < a.B ? b0 + row : a.B - 1;
+                const float* src = (arr == 0 ? a.x : arr == 1 ? a.m : a.mp) + (long)br * d + 4 * c4;
+                *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + arr * 128 + 4 * c4) = *reinterpret_cast<const f32x4*>(src);
+            }
+            {
+                const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+                const int rb = row / K;
+                const bool rok = row < a.nb * K && b0 + rb < a.B;
+                f32x4 e;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int l = 4 * qq + j;
-            const bool lok = l < L;
-            const float mu = lok ? a.heads[R * a.ldh + l] : 0.f;
-            const float lv = lok ? a.heads[R * a.ldh + L + l] : 0.f;
-            const float e = lok ? a.eps[mrow * L + l] : 0.f;
-            const float sd = __expf(0.5f * lv);
-            z[j] = lok ? mu + e * sd : 0.f;
-            ehs[j] = 0.5f * e * sd;
+                for (int j = 0; j < 4; ++j) e[j] = (rok && 4 * qd + j < L) ? a.eps[(m0 + row) * L + 4 * qd + j] : 0.f;
+                *reinterpret_cast<f32x4*>(st + ND_EPS + row * 16 + 4 * qd) = e;
+            }
+            if ((int)threadIdx.x < a.nb * 8) {
+                const int row = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, qd = threadIdx.x & 3;
+                const int br = b0 + row < a.B ? b0 + row : a.B - 1;
+                const float* src = a.heads + ((long)pass * a.B + br) * a.ldh + which * L;
+                f32x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (4 * qd + j < L) ? src[4 * qd + j] : 0.f;
+                *reinterpret_cast<f32x4*>(st + ND_HD + row * 32 + which * 16 + 4 * qd) = h;
+            }
+        }
+        ND_BARRIER();  // B0
+        // ---------------- reparameterisation (VAE.py:2385-2389): z = mean + eps * exp(logvar / 2)   (columns >= L are staged as 0)
+        f32x4 z, ehs;  // ehs = eps * exp(logvar / 2) / 2: d z / d logvar
+        {
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(st + ND_HD + blc * 32 + 4 * qq);
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(st + ND_HD + blc * 32 + 16 + 4 * qq);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(st + ND_EPS + r * 16 + 4 * qq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float esd = e[j] * __expf(0.5f * lv[j]);
+                z[j] = mu[j] + esd;
+                ehs[j] = 0.5f * esd;
+            }
         }
         const Op zb = nd_pack2(z, zero4());
+        NSTP(1);
         // ---------------- decoder forward
         Op g1b[4], g2b[4];
         {
@@ -273,50 +363,60 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         }
         launder(cc, qq);
         VPC_CUT();
-        f32x4 Y[YT];  // xm = sigmoid(.), xl = hardtanh(., -10, 0)   (VAE.py:2393-2396)
-        nd_layer_fwd<128, 4, YT>(Wx, g2b, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
+        NSTP(2);
+        // ---------------- heads + bound terms of the lane's row, pass 1: sums over the features (VAE.py:2393-2396, 2405-2440).
+        // The head outputs are NOT kept for pass 2 (64 registers across the exchange, beside its 64 registers of results): each
+        // pass forms them tile by tile on the matrix pipe - 64 bf16 MFMAs again instead of scratch traffic.
+        const float* xin = st + ND_XIN + blc * 384 + 4 * qq;  // x at + 16 t, mask at + 128, mask_p at + 256
+        struct Elems { f32x4 xv, mv, pv, sp, bj; };
+        auto fetch = [&](int t) {
+            Elems e;
+            e.xv = *reinterpret_cast<const f32x4*>(xin + 16 * t);
+            e.mv = *reinterpret_cast<const f32x4*>(xin + 128 + 16 * t);
+            e.pv = *reinterpret_cast<const f32x4*>(xin + 256 + 16 * t);
+            e.sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
+            e.bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
+            return e;
+        };
+        // xm = sigmoid(.), xl = hardtanh(., -10, 0) of the lane's 4 features of tile t
+        auto heads_act = [&](int t, f32x4 a0, f32x4 a1, f32x4& xm4, f32x4& xl4) {
+            const f32x4 p0 = a0 + *reinterpret_cast<const f32x4*>(bx + 16 * t + 4 * qq);
+            const f32x4 p1 = a1 + *reinterpret_cast<const f32x4*>(bx + 16 * (DT + t) + 4 * qq);
+            xm4 = f32x4{fast_sigmoid(p0[0]), fast_sigmoid(p0[1]), fast_sigmoid(p0[2]), fast_sigmoid(p0[3])};
+            xl4 = f32x4{fminf(fmaxf(p1[0], -10.f), 0.f), fminf(fmaxf(p1[1], -10.f), 0.f), fminf(fmaxf(p1[2], -10.f), 0.f),
+                        fminf(fmaxf(p1[3], -10.f), 0.f)};
+        };
+        float sA = 0.f, sE = 0.f, sN = 0.f;
+        {
+            Elems cur;
+            nd_heads<DT>(Wx, g2b, cc, qq, [&](int t) { cur = fetch(t); }, [&](int t, f32x4 a0, f32x4 a1) {
+                f32x4 xm4, xl4;
+                heads_act(t, a0, a1, xm4, xl4);
+                const f32x4 xv = cur.xv, mv = cur.mv, pv = cur.pv, sp = cur.sp, bj = cur.bj;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t = mt + h;
-                const f32x4 pre = (h ? a1 : a0) + *reinterpret_cast<const f32x4*>(bx + 16 * t + 4 * qq);
-                if (t < DT) {
-                    Y[t] = f32x4{fast_sigmoid(pre[0]), fast_sigmoid(pre[1]), fast_sigmoid(pre[2]), fast_sigmoid(pre[3])};
-                } else {
-                    Y[t] = f32x4{fminf(fmaxf(pre[0], -10.f), 0.f), fminf(fmaxf(pre[1], -10.f), 0.f),
-                                 fminf(fmaxf(pre[2], -10.f), 0.f), fminf(fmaxf(pre[3], -10.f), 0.f)};
+                for (int j = 0; j < 4; ++j) {
+                    const float xm = xm4[j], xl = xl4[j];
+                    const float rr = xv[j] - xm, riv = rr * __expf(-xl);
+                    const float el = 0.5f * xl + 0.5f * rr * riv;
+                    if (qpass) {
+                        sA += mv[j] * el;
+                        sE += mv[j] * (1.f - pv[j]) * el;
+                        const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
+                        const float lg = -sp[j] * (mixv - bj[j]);
+                        sN += fmaxf(lg, 0.f) - lg * mv[j] + __logf(1.f + __expf(-fabsf(lg)));
+                    } else {
+                        sA += pv[j] * el;
+                    }
                 }
-            }
-        });
+            });
+        }
         launder(cc, qq);
         VPC_CUT();
-        // ---------------- bound terms of the lane's row, pass 1: sums over the features (VAE.py:2405-2440)
-        const float* xrow = a.x + (long)bc * d + 4 * qq;
-        const float* mrowp = a.m + (long)bc * d + 4 * qq;
-        const float* mprow = a.mp + (long)bc * d + 4 * qq;
-        float sA = 0.f, sE = 0.f, sN = 0.f;
+        NSTP(3);
+        // (pass 2 must not be merged with pass 1 by common-subexpression elimination - everything it would carry across the
+        // exchange ends up in scratch: the asm makes its operand a new value)
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 16 * t);
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(mrowp + 16 * t);
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(mprow + 16 * t);
-            const f32x4 sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
-            const f32x4 bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xm = Y[t][j], xl = Y[DT + t][j];
-                const float rr = xv[j] - xm, riv = rr * __expf(-xl);
-                const float el = 0.5f * xl + 0.5f * rr * riv;
-                if (qpass) {
-                    sA += mv[j] * el;
-                    sE += mv[j] * (1.f - pv[j]) * el;
-                    const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
-                    const float lg = -sp[j] * (mixv - bj[j]);
-                    sN += fmaxf(lg, 0.f) - lg * mv[j] + __logf(1.f + __expf(-fabsf(lg)));
-                } else {
-                    sA += pv[j] * el;
-                }
-            }
-        }
+        for (int kb = 0; kb < 4; ++kb) asm volatile("" : "+v"(g2b[kb]));
         sA += __shfl_xor(sA, 16, 64); sA += __shfl_xor(sA, 32, 64);
         if (qpass) {
             sE += __shfl_xor(sE, 16, 64); sE += __shfl_xor(sE, 32, 64);
@@ -324,14 +424,32 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         }
         const float RE = sA + a.cd;
         const float lw = RE + sN;  // (the analytic KL of the data row is the same for its K replicas: it cancels in the softmax)
-        if (qq == 0) lwbuf[r] = lw;
-        ND_BARRIER();  // B1 (also: every wave is past the previous tile's dz exchange)
+        if (qq == 0 && rvalid) lwbuf[bl * KP4 + k] = lw;
+        NSTP(4);
+        ND_BARRIER();  // B1
         float wgt;     // softmax weight of the replica x the gradient weight of its pass
         {
-            float mx = -INFINITY;
-            for (int kk = 0; kk < K; ++kk) mx = fmaxf(mx, lwbuf[blc * K + kk]);
-            float s = 0.f;
-            for (int kk = 0; kk < K; ++kk) s += __expf(lwbuf[blc * K + kk] - mx);
+            const float* lwp = lwbuf + blc * KP4;
+            float mx = -INFINITY, s = 0.f;
+            if (KP4 == 20) {  // config 3's K: all five chunks in flight at once
+                f32x4 v[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) v[i] = *reinterpret_cast<const f32x4*>(lwp + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    s += (__expf(v[i][0] - mx) + __expf(v[i][1] - mx)) + (__expf(v[i][2] - mx) + __expf(v[i][3] - mx));
+            } else {
+                for (int i = 0; i < KP4; i += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(lwp + i);
+                    mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                }
+                for (int i = 0; i < KP4; i += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(lwp + i);
+                    s += (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx));
+                }
+            }
             const float lse = mx + __logf(s);
             wgt = valid ? (qpass ? a.oq : a.op) * __expf(lw - lse) : 0.f;
             if (valid && qq == 0) {
@@ -339,22 +457,21 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 if (qpass) { S[2] += sE + a.cd; S[4] += RE; }
             }
         }
+        NSTP(5);
         // ---------------- pass 2: gradients w.r.t. the head PRE-activations (through Sigmoid / Hardtanh), packed as they are made
         Op Gb[DT], E1b[DT / 2], E2b[DT / 2];
         {
             f32x4 gm_prev = zero4(), gl_prev = zero4(), e1_prev = zero4(), e2_prev = zero4();
             const float oe = valid ? a.oe : 0.f;
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 16 * t);
-                const f32x4 mv = *reinterpret_cast<const f32x4*>(mrowp + 16 * t);
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(mprow + 16 * t);
-                const f32x4 sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
-                const f32x4 bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
+            Elems cur;
+            nd_heads<DT>(Wx, g2b, cc, qq, [&](int t) { cur = fetch(t); }, [&](int t, f32x4 a0, f32x4 a1) {
+                f32x4 xm4, xl4;
+                heads_act(t, a0, a1, xm4, xl4);
+                const f32x4 xv = cur.xv, mv = cur.mv, pv = cur.pv, sp = cur.sp, bj = cur.bj;
                 f32x4 gm, gl, e1 = zero4(), e2 = zero4();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xm = Y[t][j], xl = Y[DT + t][j];
+                    const float xm = xm4[j], xl = xl4[j];
                     const float rr = xv[j] - xm, riv = rr * __expf(-xl);
                     const float h2 = 0.5f - 0.5f * rr * riv;  // d / d xl of the element NLL
                     float gxm, gxl;
@@ -382,12 +499,14 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     E2b[t >> 1] = nd_pack2(e2_prev, e2);
                 }
                 gm_prev = gm; gl_prev = gl; e1_prev = e1; e2_prev = e2;
-            }
+            });
         }
         launder(cc, qq);
         VPC_CUT();
+        NSTP(6);
         // ---------------- R1a: dWx rows of the mean head, their bias, db of the missingness model
         const int fl = 16 * qq + cc;
+        ND_BARRIER();  // B1': every wave is past its reads of the tile inputs, which the staged operands overwrite
 #pragma unroll
         for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[kb]);
 #pragma unroll
@@ -397,7 +516,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E1b[kb]);
         }
         ND_BARRIER();  // B2
-        auto round_x = [&](int half) {  // owner: wave w -> head tiles w and w + 4 of this half (DT = 8: both exist)
+        auto round_x = [&](auto half_c) {
+            constexpr int half = decltype(half_c)::value;  // owner: wave w -> head tiles w and w + 4 of this half (DT = 8: both exist)
 #pragma unroll
             for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
                 Op fb[8];
@@ -405,14 +525,14 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 for (int nt = 0; nt < 8; ++nt) fb[nt] = nd_st_frag(st, 8 + nt, kb, fl);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (w + 4 * i >= DT) continue;
+                    if (DT < 8 && w + 4 * i >= DT) continue;
                     const Op fa = nd_st_frag(st, w + 4 * i, kb, fl);
                     const int ai = 2 * half + i;
 #pragma unroll
                     for (int nt = 0; nt < 8; ++nt) accx[ai][nt] = VPC_MFMA_BF(fa, fb[nt], accx[ai][nt]);
                     accbx[ai] = VPC_MFMA_BF(fa, ones, accbx[ai]);
                 }
-                if (qpass && 2 * w < DT) {  // column sums of e1 (half 0) / e2 (half 1): tiles 2 w, 2 w + 1
+                if (qpass && (DT == 8 || 2 * w < DT)) {  // column sums of e1 (half 0) / e2 (half 1): tiles 2 w, 2 w + 1
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const Op fe = nd_st_frag(st, 16 + 2 * w + i, kb, fl);
@@ -421,7 +541,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 }
             }
         };
-        round_x(0);
+        round_x(std::integral_constant<int, 0>{});
         ND_BARRIER();  // B3
         // ---------------- R1b: the log-variance head (g2 stays in slots 8-15)
 #pragma unroll
@@ -431,9 +551,10 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E2b[kb]);
         }
         ND_BARRIER();  // B4
-        round_x(1);
+        round_x(std::integral_constant<int, 1>{});
         launder(cc, qq);
         VPC_CUT();
+        NSTP(7);
         // ---------------- dg2 = ELU'(g2) * (Wx^T G)
         Op dg2b[4];
         nd_layer_T<128, DT, ND_HT>(Wx, Gb, fl, [&](int mt, f32x4 a0, f32x4 a1) {
@@ -441,6 +562,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         });
         launder(cc, qq);
         VPC_CUT();
+        NSTP(8);
         ND_BARRIER();  // B5: every wave is past the reads of R1b
         // ---------------- R2: dW2 = dg2^T g1, db2   (owner: wave w -> out tiles 2 w, 2 w + 1)
 #pragma unroll
@@ -461,6 +583,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         }
         launder(cc, qq);
         VPC_CUT();
+        NSTP(9);
         // ---------------- dg1 = ELU'(g1) * (W2^T dg2);  dz = W1^T dg1
         Op dg1b[4];
         nd_layer_T<128, 4, ND_HT>(W2, dg2b, fl, [&](int mt, f32x4 a0, f32x4 a1) {
@@ -469,6 +592,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         f32x4 dz = zero4();
         nd_layer_T<32, 4, 1>(W1, dg1b, fl, [&](int, f32x4 a0, f32x4) { dz = a0; });
         launder(cc, qq);
+        NSTP(10);
         ND_BARRIER();  // B7
         // ---------------- R3: dW1 = dg1^T z, db1
 #pragma unroll
@@ -485,6 +609,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 accb1[i] = VPC_MFMA_BF(fa, ones, accb1[i]);
             }
         }
+        NSTP(11);
         ND_BARRIER();  // B9: the staging area becomes the dz exchange [64 rows][mean 16 | logvar 16]
         {
             float* dzx = st;
@@ -494,38 +619,38 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             *reinterpret_cast<f32x4*>(dzx + r * 32 + 16 + 4 * qq) = dl;
         }
         ND_BARRIER();  // B10
-        // ---------------- sum over the K replicas (nm_sample_bwd) + the analytic KL terms and their gradients (VAE.py:2441-2452)
-        if ((int)threadIdx.x < 16 * a.nb) {
-            const int ebl = threadIdx.x >> 4, l = threadIdx.x & 15;
+        // ---------------- sum over the K replicas (nm_sample_bwd) + the analytic KL terms and their gradients (VAE.py:2441-2452):
+        // wave w takes the data rows w, w + 4, ...; lane = (half of the replicas, mean | logvar, latent)
+        for (int ebl = w; ebl < a.nb; ebl += ND_WAVES) {
             const int eb = b0 + ebl;
-            if (eb < a.B && l < L) {
-                const float* dzx = st;
-                float sm = 0.f, sl = 0.f;
-                for (int kk = 0; kk < K; ++kk) {
-                    sm += dzx[(ebl * K + kk) * 32 + l];
-                    sl += dzx[(ebl * K + kk) * 32 + 16 + l];
-                }
+            const int col = lane & 31, part = lane >> 5, l = col & 15;
+            const float* dzx = st + ebl * K * 32 + col;
+            float sm = 0.f;
+            for (int kk = part; kk < K; kk += 2) sm += dzx[kk * 32];
+            sm += __shfl_xor(sm, 32, 64);
+            if (lane < 32 && eb < a.B && l < L) {
                 const float* hq = a.heads + (long)eb * a.ldh;
                 const float* hp = a.heads + ((long)a.B + eb) * a.ldh;
                 const float mu_q = hq[l], lv_q = hq[L + l], mu_p = hp[l], lv_p = hp[L + l];
                 const float eq = expf(lv_q), ep = expf(lv_p), ivp = expf(-lv_p), ratio = expf(lv_q - lv_p);
                 const float dm = mu_q - mu_p;
-                float gmu, glv;
+                const bool first = col < 16;  // mean lanes also carry the statistics
+                float g;
                 if (qpass) {
-                    gmu = a.kq * mu_q + a.cr * dm * ivp;
-                    glv = a.kq * 0.5f * (eq - 1.f) + a.cr * 0.5f * (ratio - 1.f);
-                    S[0] += 0.5f * (eq + mu_q * mu_q - 1.f - lv_q);
-                    S[3] += 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p));
+                    g = first ? a.kq * mu_q + a.cr * dm * ivp : a.kq * 0.5f * (eq - 1.f) + a.cr * 0.5f * (ratio - 1.f);
+                    if (first) {
+                        S[0] += 0.5f * (eq + mu_q * mu_q - 1.f - lv_q);
+                        S[3] += 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p));
+                    }
                 } else {
-                    gmu = a.kp * mu_p - a.cr * dm * ivp;
-                    glv = a.kp * 0.5f * (ep - 1.f) + a.cr * 0.5f * (1.f - ratio - dm * dm * ivp);
-                    S[1] += 0.5f * (ep + mu_p * mu_p - 1.f - lv_p);
+                    g = first ? a.kp * mu_p - a.cr * dm * ivp : a.kp * 0.5f * (ep - 1.f) + a.cr * 0.5f * (1.f - ratio - dm * dm * ivp);
+                    if (first) S[1] += 0.5f * (ep + mu_p * mu_p - 1.f - lv_p);
                 }
-                float* o = a.dht + ((long)pass * a.B + eb) * (2 * L);
-                o[l] = gmu + sm;
-                o[L + l] = glv + sl;
+                a.dht[((long)pass * a.B + eb) * (2 * L) + (first ? l : L + l)] = g + sm;
             }
         }
+        ND_BARRIER();  // B11: the exchange area is read; the next tile's inputs may land in it
+        NSTP(12);
     }
 
     // ---------------- partial block of the workgroup (register-major, coalesced) and its statistics
@@ -573,6 +698,13 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     if (threadIdx.x < ND_NSTAT)
         a.stat_part[(long)blockIdx.x * ND_NSTAT + threadIdx.x] =
             (red[threadIdx.x] + red[ND_NSTAT + threadIdx.x]) + (red[2 * ND_NSTAT + threadIdx.x] + red[3 * ND_NSTAT + threadIdx.x]);
+#ifdef VPC_ABLATE
+    NSTP(13);
+    if ((a.dbg & 64) && blockIdx.x == 7 && lane == 0 && (w == 0 || w == 3))
+        printf("nmdec blk %d wave %d: prologue %llu | load+z %llu g1g2 %llu Y %llu pass1 %llu (lw write) B1+lse %llu pass2 %llu R1a+R1b %llu dg2 %llu "
+               "B5+R2 %llu dg1+dz %llu B7+R3 %llu B9..epi %llu | partials %llu\n",
+               blockIdx.x, w, T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11], T[12], T[13]);
+#endif
 }
 
 // fixed-order reduction of the partial blocks into the flat gradient (W | b of the missingness model and the decoder segment)
