@@ -62,9 +62,12 @@ struct NdImg {
 };
 constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_LWB + 2 * ND_WAVES * ND_NSTAT) * 4;
 static_assert(ND_LDS <= 163840, "LDS budget");
-// partial block: [248 accumulator registers][256 threads]
-constexpr int ND_REGS = 248, ND_PART = ND_REGS * ND_THREADS;
-constexpr int R_X = 0, R_BX = 128, R_2 = 144, R_B2 = 208, R_1 = 216, R_B1 = 224, R_WB = 232;
+// partial block: [204 accumulator registers][256 threads]
+constexpr int ND_REGS = 204, ND_PART = ND_REGS * ND_THREADS;
+constexpr int R_X = 0, R_2 = 128, R_1 = 192, R_B = 200;
+// columns of a wave's ONE bias accumulator tile (accb, see the kernel): bx of its four head tiles, b2, b1 of its two hidden tiles
+// each, db | dW of the missingness model for its two feature tiles
+constexpr int NB_BX = 0, NB_B2 = 4, NB_B1 = 6, NB_WB = 8;
 
 typedef bf16x8 Op;
 
@@ -269,64 +272,114 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     __syncthreads();
 
     // the lane's row inside a tile: replica k of tile-local data row bl
-    const int r = 16 * w + c;
-    const int bl = r / K, k = r - bl * K;
-    const bool rvalid = r < a.nb * K;
+    const int r0 = 16 * w + c;
+    const int bl = r0 / K, k = r0 - bl * K;
+    const bool rvalid = r0 < a.nb * K;
     const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's inputs and l_w; their weights are zero)
     const int KP4 = (K + 3) & ~3;
 
-    f32x4 accx[4][8], accbx[4], acc2[2][8], accb2[2], acc1[2], accb1[2], accwb[4];
+    // Column sums over the rows (the three bias gradients, dW | db of the missingness model) come from the same staged operands as
+    // the weight gradients: an MFMA of the staged dY^T tile against a B operand whose column n is all ones and the others zero adds
+    // the tile's 16 column sums into column n of ONE accumulator tile - 4 registers for the wave's twelve such tiles instead of
+    // 4 each (with 48 more accumulators the kernel needs more than 512 registers and hipcc evicts accumulators to scratch).
+    f32x4 accx[4][8], acc2[2][8], acc1[2], accb = zero4();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accbx[i] = zero4(); accwb[i] = zero4();
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) accx[i][j] = zero4();
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        accb2[i] = zero4(); acc1[i] = zero4(); accb1[i] = zero4();
+        acc1[i] = zero4();
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc2[i][j] = zero4();
     }
     float S[ND_NSTAT] = {0.f, 0.f, 0.f, 0.f, 0.f};  // lse_q (+ KL_q), lse_p (+ KL_p), sum_k RE_e, sum_l kl_el, sum_k RE_q
-    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    const Op ones = __builtin_bit_cast(Op, ones_u);
+    auto sel_col = [&](int n, int cc) {  // B operand: column n (lanes with c == n) = eight bf16 ones, every other column zero
+        const uint32_t v = cc == n ? 0x3F803F80u : 0u;
+        return __builtin_bit_cast(Op, u32x4{v, v, v, v});
+    };
 
+    // A tile's inputs in flight: x | mask | mask_p pieces (two 16-byte pieces per thread cover nb <= 5 data rows), the eps values of
+    // one (row, quad) and the statistics of one (data row, mean | logvar, quad) per thread
+    const bool pf = a.nb * 96 <= 2 * ND_THREADS;
+    f32x4 pfx[2], pfe, pfh;
+    auto tile_origin = [&](int tile, int& pass, int& b0) {
+        pass = tile / a.tiles_per_pass;
+        b0 = (tile - pass * a.tiles_per_pass) * a.nb;
+    };
+    auto request_small = [&](int tile) {
+        int pass, b0;
+        tile_origin(tile, pass, b0);
+        const long m0 = ((long)pass * a.B + b0) * K;  // first decoder row (eps row) of the tile
+        {
+            const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+            const int rb = row / K;
+            const bool rok = row < a.nb * K && b0 + rb < a.B;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pfe[j] = (rok && 4 * qd + j < L) ? a.eps[(m0 + row) * L + 4 * qd + j] : 0.f;
+        }
+        pfh = zero4();
+        if ((int)threadIdx.x < a.nb * 8) {
+            const int row = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, qd = threadIdx.x & 3;
+            const int br = b0 + row < a.B ? b0 + row : a.B - 1;
+            const float* src = a.heads + ((long)pass * a.B + br) * a.ldh + which * L;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pfh[j] = (4 * qd + j < L) ? src[4 * qd + j] : 0.f;
+        }
+    };
+    auto request_inputs = [&](int tile) {
+        int pass, b0;
+        tile_origin(tile, pass, b0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * ND_THREADS;
+            const int ic = i < a.nb * 96 ? i : 0;
+            const int row = ic / 96, rem = ic - 96 * row, arr = rem >> 5, c4 = rem & 31;
+            const int br = b0 + row < a.B ? b0 + row : a.B - 1;
+            const float* src = (arr == 0 ? a.x : arr == 1 ? a.m : a.mp) + (long)br * d + 4 * c4;
+            pfx[u] = *reinterpret_cast<const f32x4*>(src);
+        }
+        request_small(tile);
+    };
+    auto store_small = [&](int b0) {
+        *reinterpret_cast<f32x4*>(st + ND_EPS + (threadIdx.x >> 2) * 16 + 4 * (threadIdx.x & 3)) = pfe;
+        if ((int)threadIdx.x < a.nb * 8)
+            *reinterpret_cast<f32x4*>(st + ND_HD + (threadIdx.x >> 3) * 32 + ((threadIdx.x >> 2) & 1) * 16 + 4 * (threadIdx.x & 3)) = pfh;
+    };
+    auto store_inputs = [&](int b0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * ND_THREADS;
+            if (i < a.nb * 96) {
+                const int row = i / 96, rem = i - 96 * row;
+                *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + 4 * rem) = pfx[u];
+            }
+        }
+        store_small(b0);
+    };
+    if (pf && (int)blockIdx.x < a.ntiles) request_inputs(blockIdx.x);
     NSTP(0);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
         launder(cc, qq);
+        const int r = 16 * w + cc;  // (from the laundered lane id: what hangs off it is re-derived per tile, not kept across the loop)
         const int pass = tile / a.tiles_per_pass;
         const bool qpass = pass == 0;
         const int b0 = (tile - pass * a.tiles_per_pass) * a.nb;
         const int b = b0 + bl;
         const bool valid = rvalid && b < a.B;
-        // ---------------- the tile's inputs -> LDS, once per tile (every replica of a data row reads the same x / masks / statistics)
-        {
-            const long m0 = ((long)pass * a.B + b0) * K;  // first decoder row (eps row) of the tile
+        // ---------------- the tile's inputs -> LDS, once per tile (every replica of a data row reads the same x / masks / statistics);
+        // they were requested from global memory while the previous tile's staging rounds ran (request_inputs below)
+        if (pf) {
+            store_inputs(b0);
+        } else {  // many data rows per tile (K < 13): more than two 16-byte pieces per thread - loaded here, latency exposed
+            request_small(tile);
+            store_small(b0);
             for (int i = threadIdx.x; i < a.nb * 96; i += ND_THREADS) {
                 const int row = i / 96, rem = i - 96 * row, arr = rem >> 5, c4 = rem & 31;
                 const int br = b0 + row < a.B ? b0 + row : a.B - 1;
                 const float* src = (arr == 0 ? a.x : arr == 1 ? a.m : a.mp) + (long)br * d + 4 * c4;
                 *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + arr * 128 + 4 * c4) = *reinterpret_cast<const f32x4*>(src);
-            }
-            {
-                const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
-                const int rb = row / K;
-                const bool rok = row < a.nb * K && b0 + rb < a.B;
-                f32x4 e;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = (rok && 4 * qd + j < L) ? a.eps[(m0 + row) * L + 4 * qd + j] : 0.f;
-                *reinterpret_cast<f32x4*>(st + ND_EPS + row * 16 + 4 * qd) = e;
-            }
-            if ((int)threadIdx.x < a.nb * 8) {
-                const int row = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, qd = threadIdx.x & 3;
-                const int br = b0 + row < a.B ? b0 + row : a.B - 1;
-                const float* src = a.heads + ((long)pass * a.B + br) * a.ldh + which * L;
-                f32x4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (4 * qd + j < L) ? src[4 * qd + j] : 0.f;
-                *reinterpret_cast<f32x4*>(st + ND_HD + row * 32 + which * 16 + 4 * qd) = h;
             }
         }
         ND_BARRIER();  // B0
@@ -346,14 +399,20 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         const Op zb = nd_pack2(z, zero4());
         NSTP(1);
         // ---------------- decoder forward
-        Op g1b[4], g2b[4];
-        {
-            const Op zin[1] = {zb};
+        // g1 = ELU(W1 z + b1) is formed here for the forward and AGAIN in front of R2 (8 MFMAs + the ELUs instead of 16 registers
+        // held across the loss passes and R1, the phases with the most live state)
+        const Op zin[1] = {zb};
+        auto make_g1 = [&](Op (&g1b)[4]) {
             nd_layer_fwd<32, 1, ND_HT>(W1, zin, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
                 const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq));
                 const f32x4 h1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 16 + 4 * qq));
                 g1b[mt >> 1] = nd_pack2(h0, h1);
             });
+        };
+        Op g2b[4];
+        {
+            Op g1b[4];
+            make_g1(g1b);
             launder(cc, qq);
             nd_layer_fwd<128, 4, ND_HT>(W2, g1b, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
                 const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 4 * qq));
@@ -507,6 +566,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- R1a: dWx rows of the mean head, their bias, db of the missingness model
         const int fl = 16 * qq + cc;
         ND_BARRIER();  // B1': every wave is past its reads of the tile inputs, which the staged operands overwrite
+        if (pf && tile + (int)gridDim.x < a.ntiles) request_inputs(tile + gridDim.x);  // (arrive under the staging rounds)
 #pragma unroll
         for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[kb]);
 #pragma unroll
@@ -530,13 +590,13 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     const int ai = 2 * half + i;
 #pragma unroll
                     for (int nt = 0; nt < 8; ++nt) accx[ai][nt] = VPC_MFMA_BF(fa, fb[nt], accx[ai][nt]);
-                    accbx[ai] = VPC_MFMA_BF(fa, ones, accbx[ai]);
+                    accb = VPC_MFMA_BF(fa, sel_col(NB_BX + ai, cc), accb);
                 }
                 if (qpass && (DT == 8 || 2 * w < DT)) {  // column sums of e1 (half 0) / e2 (half 1): tiles 2 w, 2 w + 1
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const Op fe = nd_st_frag(st, 16 + 2 * w + i, kb, fl);
-                        accwb[2 * half + i] = VPC_MFMA_BF(fe, ones, accwb[2 * half + i]);
+                        accb = VPC_MFMA_BF(fe, sel_col(NB_WB + 2 * half + i, cc), accb);
                     }
                 }
             }
@@ -563,6 +623,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         launder(cc, qq);
         VPC_CUT();
         NSTP(8);
+        Op g1b[4];
+        make_g1(g1b);
+        launder(cc, qq);
         ND_BARRIER();  // B5: every wave is past the reads of R1b
         // ---------------- R2: dW2 = dg2^T g1, db2   (owner: wave w -> out tiles 2 w, 2 w + 1)
 #pragma unroll
@@ -578,7 +641,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 const Op fa = nd_st_frag(st, 2 * w + i, kb, fl);
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) acc2[i][nt] = VPC_MFMA_BF(fa, fb[nt], acc2[i][nt]);
-                accb2[i] = VPC_MFMA_BF(fa, ones, accb2[i]);
+                accb = VPC_MFMA_BF(fa, sel_col(NB_B2 + i, cc), accb);
             }
         }
         launder(cc, qq);
@@ -606,7 +669,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             for (int i = 0; i < 2; ++i) {
                 const Op fa = nd_st_frag(st, 2 * w + i, kb, fl);
                 acc1[i] = VPC_MFMA_BF(fa, fb, acc1[i]);
-                accb1[i] = VPC_MFMA_BF(fa, ones, accb1[i]);
+                accb = VPC_MFMA_BF(fa, sel_col(NB_B1 + i, cc), accb);
             }
         }
         NSTP(11);
@@ -662,10 +725,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[(R_X + (8 * i + nt) * 4 + j) * ND_THREADS] = accx[i][nt][j];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part[(R_BX + 4 * i + j) * ND_THREADS] = accbx[i][j];
-#pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
@@ -674,20 +733,19 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            part[(R_B2 + 4 * i + j) * ND_THREADS] = accb2[i][j];
-            part[(R_1 + 4 * i + j) * ND_THREADS] = acc1[i][j];
-            part[(R_B1 + 4 * i + j) * ND_THREADS] = accb1[i][j];
-        }
-    // missingness model: accwb[i] = sum over rows of e1 (i < 2: features 16 (2 w + i) + 4 q + j) / e2 (i >= 2);
+        for (int j = 0; j < 4; ++j) part[(R_1 + 4 * i + j) * ND_THREADS] = acc1[i][j];
+    // the bias tile: lane column c = NB_* + index, rows 4 q + j = the feature inside its tile.  Missingness model (columns
+    // NB_WB + i2: i2 < 2 sums of e1, i2 >= 2 sums of e2 over the rows, features 16 (2 w + (i2 & 1)) + 4 q + j):
     // db = softplus(W) * sum e1, dW = -sigmoid(W) * sum e2   (VAE.py:2424-2431 through autograd)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = (16 * (2 * w + (i & 1)) + 4 * q + j) & 127;
-            part[(R_WB + 4 * i + j) * ND_THREADS] = (i < 2) ? SP[f] * accwb[i][j] : -SG[f] * accwb[i][j];
+    for (int j = 0; j < 4; ++j) {
+        float v = accb[j];
+        if (c >= NB_WB && c < NB_WB + 4) {
+            const int i2 = c - NB_WB, f = (16 * (2 * w + (i2 & 1)) + 4 * q + j) & 127;
+            v *= (i2 < 2) ? SP[f] : -SG[f];
         }
+        part[(R_B + j) * ND_THREADS] = v;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ND_NSTAT; ++i) {
@@ -804,13 +862,13 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
     for (int i = 0; i < n; ++i) { pack_idx[i] = INT_MIN; grad_idx[i] = -1; }
     // position inside a partial block of accumulator register `reg` of thread (wave w, lane 16 q + c)
     auto pos = [](int reg, int w, int q, int c) { return reg * ND_THREADS + 64 * w + 16 * q + c; };
-    // missingness model: accwb[i] of wave w: features 16 (2 w + (i & 1)) + 4 q + j; i < 2 -> db, i >= 2 -> dW
+    // missingness model: columns NB_WB + i (db) / NB_WB + 2 + i (dW) of wave w's bias tile: features 16 (2 w + i) + 4 q + j
     for (int f = 0; f < d; ++f) {
         const int t = f >> 4, w = t >> 1, i = t & 1, q = (f >> 2) & 3, j = f & 3;
         pack_idx[f] = -(NdImg::oWm + f + 1);
         pack_idx[d + f] = -(NdImg::oBm + f + 1);
-        grad_idx[f] = pos(R_WB + 4 * (2 + i) + j, w, q, 0);
-        grad_idx[d + f] = pos(R_WB + 4 * i + j, w, q, 0);
+        grad_idx[f] = pos(R_B + j, w, q, NB_WB + 2 + i);
+        grad_idx[d + f] = pos(R_B + j, w, q, NB_WB + i);
     }
     int o = 2 * d + n_enc;
     const int oWd1 = o, obd1 = oWd1 + hid * L, oWd2 = obd1 + hid, obd2 = oWd2 + hid * hid, oWx = obd2 + hid,
@@ -822,13 +880,13 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
             grad_idx[oWd1 + r * L + f] = pos(R_1 + 4 * i + j, w, q, f);
         }
         pack_idx[obd1 + r] = -(NdImg::ob1 + r + 1);
-        grad_idx[obd1 + r] = pos(R_B1 + 4 * i + j, w, q, 0);
+        grad_idx[obd1 + r] = pos(R_B + j, w, q, NB_B1 + i);
         for (int f = 0; f < hid; ++f) {
             pack_idx[oWd2 + r * hid + f] = 2 * NdImg::oW2 + nd_elem<128>(r, f);
             grad_idx[oWd2 + r * hid + f] = pos(R_2 + (8 * i + (f >> 4)) * 4 + j, w, q, f & 15);
         }
         pack_idx[obd2 + r] = -(NdImg::ob2 + r + 1);
-        grad_idx[obd2 + r] = pos(R_B2 + 4 * i + j, w, q, 0);
+        grad_idx[obd2 + r] = pos(R_B + j, w, q, NB_B2 + i);
     }
     for (int r = 0; r < 2 * d; ++r) {  // head rows: tile t = r >> 4; half = t / 8, owner wave (t & 7) & 3, slot i = (t & 7) >> 2
         const int t = r >> 4, half = t >> 3, tt = t & 7, w = tt & 3, i = tt >> 2, ai = 2 * half + i, q = (r >> 2) & 3, j = r & 3;
@@ -837,7 +895,7 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
             grad_idx[oWx + r * hid + f] = pos(R_X + (8 * ai + (f >> 4)) * 4 + j, w, q, f & 15);
         }
         pack_idx[obx + r] = -(NdImg::obx + r + 1);
-        grad_idx[obx + r] = pos(R_BX + 4 * ai + j, w, q, 0);
+        grad_idx[obx + r] = pos(R_B + j, w, q, NB_BX + ai);
     }
     return VPC_OK;
 }
