@@ -158,3 +158,30 @@ def test_fused_and_gemm_trajectories_agree(monkeypatch):
     # they may differ by up to 2 * 5 * lr where a gradient changes sign - bounded, not compared tightly)
     assert float(np.max(np.abs(runs["fused"][2] - runs["gemm"][2]))) <= 2 * 5 * 1e-3
     assert lf[-1] < lf[0]
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_fused():
+    """step_graph (captured HIP graph, device-side step / Philox counters bumped by the fused kernel's finalize) is
+    bit-identical to the eager sequence of the fused form; and two runs of the eager form are bit-identical to each other
+    (fixed-order reduction of the partial blocks: no atomics anywhere)."""
+    from vpc_amd import notmiwae as nm
+    B, d, K, L = 128, 128, 20, 10
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(B, d, device="cuda", generator=g)
+    m = (torch.rand(B, d, device="cuda", generator=g) < 0.6).float()
+    res = []
+    for mode in ("eager", "graph", "eager"):
+        torch.manual_seed(11)
+        model = nm.REG_notMIWAE_v2(d, 500, 10, L, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, lr=1e-3, seed=5, precision="bf16")
+        losses = []
+        for _ in range(6):
+            (tr.step if mode == "eager" else tr.step_graph)(x, m, alpha=0.5, p_missingness=50)
+            losses.append(tr.loss_value())
+        assert tr.use_nmdec
+        res.append((losses, model._flat.clone(), tr.epoch_total()))
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        assert torch.equal(res[0][1], other[1])
+        assert res[0][2] == other[2]
