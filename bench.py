@@ -379,6 +379,7 @@ def extra_configs(vpc, dev):
             f3 = mnar_flops_per_sample(d, Ld, K)
             out.append(dict(config=3, workload="UCI gas stand-in (MNAR), REG_notMIWAE_v2 K=20, batch 128, p_missingness 50",
                             dtype=prec, us_per_step=dt * 1e6, samples_per_s=128 / dt,
+                            decoder="layer-fused kernel (csrc/vpc_nmdec.hip)" if tr.use_nmdec else "GEMM chain",
                             roofline=dict(bound="mfma", achieved=f3 * 128 / dt / 1e12, peak=PEAK[prec], unit="TFLOP/s",
                                           frac=f3 * 128 / dt / 1e12 / PEAK[prec], note="whole step")))
             del tr, model
