@@ -934,13 +934,7 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
     const int cap = num_cus();
     const int blocks = a.ntiles < cap ? a.ntiles : cap;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nmdec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ND_LDS) !=
-            hipSuccess)
-            return VPC_ERR_HIP;
-        attr_done = true;
-    }
+    if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8>), ND_LDS)) return VPC_ERR_HIP;
     hipLaunchKernelGGL((nmdec_kernel<8>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
     NmdFinArgs f{};
