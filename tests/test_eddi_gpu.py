@@ -285,3 +285,36 @@ def test_front_end_stacked_passes(ed):
     ed.eddi_front_bwd(x, m1, AC, dagg[B:].contiguous(), E, tb, Wp, *gs, B, d, K, accumulate=True)
     for a, b in zip(g2, gs):
         _close(a, b, 2e-6, "stacked vs per-pass gradients")
+
+
+def test_with_drop_variant_runs_the_fused_step(ed, tmp_path, monkeypatch):
+    """'vanilla_EDDI*_with_drop' (train.py:32-37, 50-51, 95-101; utils.py:42-45): the model is trained on mask * mask_drop.  train()
+    now runs that variant as the fused vanilla step on the thinned mask (r02: API path only).  With the same drop masks injected
+    the fused form and the reference's own forward -> loss -> backward -> Adam sequence on the API path follow the same
+    trajectory, and the keep-mask has the reference's distribution."""
+    import vpc_amd
+    from vpc_amd import harness
+    from torch.utils.data import DataLoader, TensorDataset
+    monkeypatch.chdir(tmp_path)
+    md = vpc_amd.create_missing_uci_drop_eddi((4000, 50))
+    assert md.dtype == torch.float32 and set(md.unique().tolist()) <= {0.0, 1.0}
+    assert abs(float(md.mean()) - 0.50005) < 0.01  # 1 - E[min(U, .99)]
+    torch.manual_seed(0)
+    x = torch.rand(96, 14)
+    m = torch.rand(96, 14) < 0.7
+    loader = DataLoader(TensorDataset(x, m), batch_size=32, shuffle=False)
+    tp = {"batch_size": 32, "patience": 1}
+    drops = [(torch.rand(32, 14, generator=torch.Generator().manual_seed(100 + i)) < 0.5).float().cuda() for i in range(9)]
+    finals = {}
+    for fused in (True, False):
+        it = iter(drops)
+        monkeypatch.setattr(harness, "create_missing_uci_drop_eddi", lambda shape, device="cuda", generator=None: next(it))
+        torch.manual_seed(1)
+        model = vpc_amd.train((loader, None), 30, 14, 500, 10, 1, 10, "toy", tp, "exp", "vanilla_EDDI1_with_drop", 1, 1,
+                              max_epochs=3, verbose=False, save=False, fused=fused, seed=3)
+        finals[fused] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # (eps differs between the two forms - device Philox vs torch.randn - so the weights agree statistically, not bitwise: both
+    # moved away from the common initialisation by the same nine Adam steps on the same thinned masks)
+    for k in finals[True]:
+        a, b = finals[True][k].float(), finals[False][k].float()
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2 * 9 * 1e-3 + 1e-6, k

@@ -9,7 +9,7 @@ from ._lib import VpcError, LIB_PATH
 from .models import Reg_VAE, vanilla_VAE, Reg_VAE_mask, vanilla_VAE_mask, MAX_EPOCH
 from .fused import FusedTrainer
 from .notmiwae import REG_notMIWAE_v2, notMIWAE_myversion, NMTrainer
-from .harness import (create_missing_uci, model_loader, checkpoint_path, train, eval_vae, result_paths, eval_vae_mnar,
+from .harness import (create_missing_uci, create_missing_uci_drop_eddi, model_loader, checkpoint_path, train, eval_vae, result_paths, eval_vae_mnar,
                       mnar_result_path)
 from . import notmiwae
 from . import eddi
@@ -23,6 +23,6 @@ from .active import (reward_matrix, R_lindley_chain, chaini_I, chaini_II, active
                      mc_forward)
 
 __all__ = ["Reg_VAE", "vanilla_VAE", "Reg_VAE_mask", "vanilla_VAE_mask", "FusedTrainer", "REG_notMIWAE_v2",
-           "notMIWAE_myversion", "NMTrainer", "notmiwae", "eddi", "Reg_EDDI", "vanilla_EDDI", "EDDITrainer", "eval_vae_mnar", "mnar_result_path", "create_missing_uci", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
+           "notMIWAE_myversion", "NMTrainer", "notmiwae", "eddi", "Reg_EDDI", "vanilla_EDDI", "EDDITrainer", "eval_vae_mnar", "mnar_result_path", "create_missing_uci", "create_missing_uci_drop_eddi", "model_loader", "checkpoint_path", "train", "eval_vae", "result_paths",
            "VpcError", "ops", "dp", "LIB_PATH", "MAX_EPOCH", "active", "reward_matrix", "R_lindley_chain", "chaini_I",
            "chaini_II"]

@@ -38,6 +38,14 @@ def create_missing_uci(shape, missing_rate, device="cuda", seed=None, offset=0):
     return out.view(torch.bool)
 
 
+def create_missing_uci_drop_eddi(shape, device="cuda", generator=None):
+    """Per-element keep-mask of the 'with_drop' variants (utils.py:42-45): keep ~ Bernoulli(1 - min(U, 0.99)) with its own U per
+    element, drawn on the device as a float 0 / 1 tensor (the reference draws numpy / scipy variates on the host; only the
+    distribution is reproducible - marginally P(keep) = 1 - E[min(U, .99)] = 0.50005)."""
+    keep_p = 1.0 - torch.rand(tuple(shape), device=device, generator=generator).clamp_(max=0.99)
+    return (torch.rand(tuple(shape), device=device, generator=generator) < keep_p).float()
+
+
 def _family(vae_type: str) -> str:
     # train.py:122-124: first two '_' tokens of vae_type with the digits removed
     return "".join(ch for ch in "_".join(vae_type.split("_")[:2]) if not ch.isdigit())
@@ -104,8 +112,9 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
     loader = data_loader_train if nm else data_loader_train[0]  # train.py:22-25
     is_reg = "reg" in vae_type
     eddi = "EDDI" in vae_type
-    if eddi and "with_drop" in vae_type:
-        fused = False  # the per-element keep-mask of the with_drop variants is applied on the API path
+    # 'with_drop' variants (train.py:32-37, 50-51; vanilla classes only - the reference's regularised branch never draws mask_p
+    # beside it): the model sees mask * mask_drop, the keep-mask of create_missing_uci_drop_eddi (utils.py:42-45)
+    drop = "with_drop" in vae_type and not is_reg
     if fused:
         if getattr(model, "_wide", False):  # encoder input > 128 columns: the generic-GEMM step (wide.py)
             from .wide import WideTrainer
@@ -120,6 +129,8 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
         for data_sample, mask in loader:
             data_sample = data_sample.to(device)
             mask = mask.to(device)
+            if fused and drop:  # the fused vanilla step on the thinned mask (one more elementwise launch, no host sync)
+                mask = mask.to(torch.float32) * create_missing_uci_drop_eddi(data_sample.shape, device=device)
             if fused and nm:
                 trainer.step(data_sample, mask, alpha=alpha, p_missingness=p_missingness)
                 continue
@@ -136,9 +147,8 @@ def train(data_loader_train, missing_rate, obs_dim, hid_dim, K, M, latent_dim, d
                                            i + 1, beta_annealing=beta_annealing, beta=beta, alpha=alpha,
                                            alpha_annealing=alpha_annealing, stage=stage)
             else:  # train.py:50-51, 58, 95-101
-                if "with_drop" in vae_type:  # create_missing_uci_drop_eddi (utils.py:42-45): keep ~ Bern(1 - min(U, .99))
-                    keep_p = 1.0 - torch.rand(data_sample.shape, device=device).clamp_(max=0.99)
-                    mask_drop = (torch.rand(data_sample.shape, device=device) < keep_p).float()
+                if drop:
+                    mask_drop = create_missing_uci_drop_eddi(data_sample.shape, device=device)
                 else:
                     mask_drop = torch.ones(data_sample.shape, device=device)
                 o = model.forward(data_sample, mask * mask_drop)
