@@ -616,3 +616,28 @@ def test_graph_replay_matches_eager_steps(cls):
     x2 = torch.rand(B, d, device=DEV)
     t1.step(x2, md, alpha=0.9, beta=0.8); t2.step_graph(x2, md, alpha=0.9, beta=0.8)
     assert torch.equal(m1._flat, m2._flat)
+
+
+@pytest.mark.parametrize("prec,tile,B", [("f32", None, 64), ("f32", "64", 200), ("bf16", "128", 300), ("bf16", None, 64)])
+def test_graph_replay_matches_eager_steps_d128(prec, tile, B, monkeypatch):
+    """The same at obs_dim 128 in every form of the step: the N-split kernel (B = 64, fp32), the three small-shape kernels, the
+    whole-step bf16 kernel (its compact image is re-packed inside the graph) and the small-shape bf16 kernels - bitwise equal
+    weights after six steps, fresh noise on every replay."""
+    if tile:
+        monkeypatch.setenv("VPC_TILE", tile)
+    d = 128
+    params = O.init_params(d, L, seed=9)
+    x, mask, _, _, _ = synth(B, d, seed=4)
+    xd, md = x.to(DEV), mask.to(DEV)
+    m1, m2 = make_model(vpc.Reg_VAE, d, params), make_model(vpc.Reg_VAE, d, params)
+    t1, t2 = vpc.FusedTrainer(m1, seed=3, precision=prec), vpc.FusedTrainer(m2, seed=3, precision=prec)
+    seen = []
+    for i in range(6):
+        t1.step(xd, md, alpha=0.9, beta=0.8)
+        t2.step_graph(xd, md, alpha=0.9, beta=0.8)
+        assert t1.loss_value() == t2.loss_value(), i
+        seen.append(t2.eps_buf[0].clone())
+    assert t1.dominant_launch() == t2.dominant_launch()
+    assert all(not torch.equal(a, b) for a, b in zip(seen, seen[1:]))
+    assert torch.equal(m1._flat, m2._flat)
+    assert int(t2.state[0]) == 6  # steps done: one eager warm-up + five replays

@@ -321,6 +321,11 @@ class FusedTrainer:
                         loss_in=self.out9 if self.dp else None, accum=self.accum if self.dp else None)
             if self.prec:
                 self._stale = {"pair": True, "step": True}
+            if use_step and _state is not None:
+                # graph capture: the lazy re-pack at the start of the next eager step is not part of a replay - the compact
+                # image of the whole-step kernel is re-packed here, inside the captured sequence
+                ops.step_pack_weights_bf16(m._flat, self.pidx_c, self.img_c)
+                self._stale["step"] = False
         elif self.dp:
             self.accum += self.out9[0]
 
