@@ -45,13 +45,17 @@ VPC_HD constexpr int nd_elem(int row, int f) {  // u16 index of (row, input feat
 }
 
 constexpr int ND_WAVES = 4, ND_THREADS = 256, ND_ROWS = 64, ND_HID = 128, ND_HT = 8;
-constexpr int ND_FT = 24;                                  // staging slots per row
-constexpr int ND_ST_DW = (ND_ROWS / 8) * ND_FT * 64;       // 12 288 dwords
+constexpr int ND_FT = 25;                                  // staging slots per row
+constexpr int ND_ST_DW = (ND_ROWS / 8) * ND_FT * 64;       // 12 800 dwords
+constexpr int ND_RB_DW = ND_FT * 64;                       // one 8-row block of the staging area
 constexpr int ND_NSTAT = 5;
 // a tile's inputs, staged once per tile by the whole workgroup in the (then idle) staging area: x | mask | mask_p rows of its data
 // rows, the eps rows of its replicas (padded to 16), the (mean | logvar) rows of its data rows (16 | 16)
-constexpr int ND_XIN = 0, ND_EPS = ND_XIN + 16 * 3 * 128, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + 16 * 32;
+// (from the third 8-row block on: the first two hold the dz exchange of the previous tile while the next one's inputs land)
+constexpr int ND_XIN = 2 * ND_RB_DW, ND_EPS = ND_XIN + 16 * 3 * 128, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + 16 * 32;
 static_assert(ND_IN_DW <= ND_ST_DW, "tile inputs alias the staging area");
+// dz exchange [64 rows][mean 16 | logvar 16]: 32 rows per 8-row block of the staging area, in the dwords of its slots 0-15
+__host__ __device__ constexpr int nd_dzx(int row) { return (row >> 5) * ND_RB_DW + (row & 31) * 32; }
 constexpr int ND_LWB = 128;  // l_w exchange: data-row groups of (K + 3) & ~3 floats, unused entries stay -inf
 // dword offsets inside the image (global and LDS): bf16 layers, fp32 biases, raw W / b of the missingness model; LDS only: their
 // softplus / sigmoid
@@ -307,20 +311,28 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         pass = tile / a.tiles_per_pass;
         b0 = (tile - pass * a.tiles_per_pass) * a.nb;
     };
+    // (the thread id is made opaque in each of these: their address arithmetic - divisions by 96 and K included - is otherwise
+    // hoisted out of the tile loop, and what is hoisted lives in scratch: ~20 reloads per tile)
+    auto opaque_tid = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
     auto request_small = [&](int tile) {
         int pass, b0;
         tile_origin(tile, pass, b0);
         const long m0 = ((long)pass * a.B + b0) * K;  // first decoder row (eps row) of the tile
+        const int tid = opaque_tid();
         {
-            const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+            const int row = tid >> 2, qd = tid & 3;
             const int rb = row / K;
             const bool rok = row < a.nb * K && b0 + rb < a.B;
 #pragma unroll
             for (int j = 0; j < 4; ++j) pfe[j] = (rok && 4 * qd + j < L) ? a.eps[(m0 + row) * L + 4 * qd + j] : 0.f;
         }
         pfh = zero4();
-        if ((int)threadIdx.x < a.nb * 8) {
-            const int row = threadIdx.x >> 3, which = (threadIdx.x >> 2) & 1, qd = threadIdx.x & 3;
+        if (tid < a.nb * 8) {
+            const int row = tid >> 3, which = (tid >> 2) & 1, qd = tid & 3;
             const int br = b0 + row < a.B ? b0 + row : a.B - 1;
             const float* src = a.heads + ((long)pass * a.B + br) * a.ldh + which * L;
 #pragma unroll
@@ -330,9 +342,10 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     auto request_inputs = [&](int tile) {
         int pass, b0;
         tile_origin(tile, pass, b0);
+        const int tid = opaque_tid();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = threadIdx.x + u * ND_THREADS;
+            const int i = tid + u * ND_THREADS;
             const int ic = i < a.nb * 96 ? i : 0;
             const int row = ic / 96, rem = ic - 96 * row, arr = rem >> 5, c4 = rem & 31;
             const int br = b0 + row < a.B ? b0 + row : a.B - 1;
@@ -342,14 +355,15 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         request_small(tile);
     };
     auto store_small = [&](int b0) {
-        *reinterpret_cast<f32x4*>(st + ND_EPS + (threadIdx.x >> 2) * 16 + 4 * (threadIdx.x & 3)) = pfe;
-        if ((int)threadIdx.x < a.nb * 8)
-            *reinterpret_cast<f32x4*>(st + ND_HD + (threadIdx.x >> 3) * 32 + ((threadIdx.x >> 2) & 1) * 16 + 4 * (threadIdx.x & 3)) = pfh;
+        const int tid = opaque_tid();
+        *reinterpret_cast<f32x4*>(st + ND_EPS + (tid >> 2) * 16 + 4 * (tid & 3)) = pfe;
+        if (tid < a.nb * 8) *reinterpret_cast<f32x4*>(st + ND_HD + (tid >> 3) * 32 + ((tid >> 2) & 1) * 16 + 4 * (tid & 3)) = pfh;
     };
     auto store_inputs = [&](int b0) {
+        const int tid = opaque_tid();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = threadIdx.x + u * ND_THREADS;
+            const int i = tid + u * ND_THREADS;
             if (i < a.nb * 96) {
                 const int row = i / 96, rem = i - 96 * row;
                 *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + 4 * rem) = pfx[u];
@@ -630,6 +644,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- R2: dW2 = dg2^T g1, db2   (owner: wave w -> out tiles 2 w, 2 w + 1)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) { nd_st_op(st, r, 0, kb, qq, dg2b[kb]); nd_st_op(st, r, 8, kb, qq, g1b[kb]); }
+        nd_st_op<false>(st, r, 24, 0, qq, zb);  // (R3's second operand: slot 24 is read by nobody until then)
         ND_BARRIER();  // B6
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
@@ -656,30 +671,28 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         nd_layer_T<32, 4, 1>(W1, dg1b, fl, [&](int, f32x4 a0, f32x4) { dz = a0; });
         launder(cc, qq);
         NSTP(10);
-        ND_BARRIER();  // B7
-        // ---------------- R3: dW1 = dg1^T z, db1
+        // ---------------- R3: dW1 = dg1^T z, db1.  dg1 goes to slots 16-23, which R2 does not read: no barrier in front of the writes
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) nd_st_op(st, r, 0, kb, qq, dg1b[kb]);
-        nd_st_op<false>(st, r, 8, 0, qq, zb);
+        for (int kb = 0; kb < 4; ++kb) nd_st_op(st, r, 16, kb, qq, dg1b[kb]);
         ND_BARRIER();  // B8
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
-            const Op fb = nd_st_frag(st, 8, kb, fl);
+            const Op fb = nd_st_frag(st, 24, kb, fl);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const Op fa = nd_st_frag(st, 2 * w + i, kb, fl);
+                const Op fa = nd_st_frag(st, 16 + 2 * w + i, kb, fl);
                 acc1[i] = VPC_MFMA_BF(fa, fb, acc1[i]);
                 accb = VPC_MFMA_BF(fa, sel_col(NB_B1 + i, cc), accb);
             }
         }
         NSTP(11);
-        ND_BARRIER();  // B9: the staging area becomes the dz exchange [64 rows][mean 16 | logvar 16]
+        // the dz exchange lives in the dwords of slots 0-15 (all reads of R2 are behind B8): no barrier in front of the writes either
         {
-            float* dzx = st;
+            float* dzx = st + nd_dzx(r);
             const f32x4 dm = valid ? dz : zero4();
             const f32x4 dl = valid ? dz * ehs : zero4();
-            *reinterpret_cast<f32x4*>(dzx + r * 32 + 4 * qq) = dm;
-            *reinterpret_cast<f32x4*>(dzx + r * 32 + 16 + 4 * qq) = dl;
+            *reinterpret_cast<f32x4*>(dzx + 4 * qq) = dm;
+            *reinterpret_cast<f32x4*>(dzx + 16 + 4 * qq) = dl;
         }
         ND_BARRIER();  // B10
         // ---------------- sum over the K replicas (nm_sample_bwd) + the analytic KL terms and their gradients (VAE.py:2441-2452):
@@ -687,9 +700,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         for (int ebl = w; ebl < a.nb; ebl += ND_WAVES) {
             const int eb = b0 + ebl;
             const int col = lane & 31, part = lane >> 5, l = col & 15;
-            const float* dzx = st + ebl * K * 32 + col;
             float sm = 0.f;
-            for (int kk = part; kk < K; kk += 2) sm += dzx[kk * 32];
+            for (int kk = part; kk < K; kk += 2) sm += st[nd_dzx(ebl * K + kk) + col];
             sm += __shfl_xor(sm, 32, 64);
             if (lane < 32 && eb < a.B && l < L) {
                 const float* hq = a.heads + (long)eb * a.ldh;
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 a.dht[((long)pass * a.B + eb) * (2 * L) + (first ? l : L + l)] = g + sm;
             }
         }
-        ND_BARRIER();  // B11: the exchange area is read; the next tile's inputs may land in it
+        // (no barrier: the next tile's inputs land behind the exchange area, and whoever stores them is past B10)
         NSTP(12);
     }
 
