@@ -321,7 +321,7 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
                 long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream);
 
 /* ---- layer-fused K-fold decoder of the regularised MNAR step, plain bf16 MFMA inputs (csrc/vpc_nmdec.hip) ----------
- * Replaces, for REG_notMIWAE_v2 at obs_dim = 128 (latent_dim <= 15, 4 <= K <= 64; hidden width 128), the launches
+ * Replaces, for REG_notMIWAE_v2 at obs_dim = 128 (latent_dim <= 15, 8 <= K <= 64; hidden width 128), the launches
  *   vpc_nm_sample -> 3 x vpc_linear_fwd -> vpc_nm_loss -> 3 x (vpc_linear_wgrad, vpc_linear_dgrad) -> vpc_nm_sample_bwd
  * of one training step with precision = 2 (src/models/VAE.py:2382-2396 K-fold rsample + decoder, :2398-2471 loss, and
  * their autograd, src/experiment_main/train.py:115): the K replicas of a few data rows are one workgroup tile, and no

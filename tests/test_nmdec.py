@@ -112,11 +112,11 @@ def _trainer_vs_oracle(d, L, K, B, alpha, seed=5):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,K,L,alpha", [(128, 20, 10, 0.5), (37, 20, 10, 1.0), (3, 20, 10, 0.3), (1000, 20, 10, 0.5),
-                                         (50, 7, 5, 0.5), (20, 64, 15, 0.7), (33, 4, 1, 0.5)])
+                                         (50, 11, 5, 0.5), (20, 64, 15, 0.7), (33, 8, 1, 0.5)])
 def test_fused_decoder_vs_emulating_oracle(B, K, L, alpha):
     """config 3's shape (d = 128, K = 20, batch 128), ragged last tiles (37 = 12 x 3 + 1 data rows per pass), a batch smaller
     than one tile, many tiles per workgroup (1000 rows -> 668 tiles on 256 CUs), and the extremes of K / latent size the
-    kernel accepts (K = 7: 9 data rows per tile; K = 64: one; K = 4: 16)."""
+    kernel accepts (K = 8: 8 data rows per tile; K = 64: one), K = 11 with 5 rows and 9 padding rows."""
     tr = _trainer_vs_oracle(128, L, K, B, alpha)
     assert tr.use_nmdec
 

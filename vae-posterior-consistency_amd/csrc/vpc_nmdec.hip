@@ -52,7 +52,8 @@ constexpr int ND_NSTAT = 5;
 // a tile's inputs, staged once per tile by the whole workgroup in the (then idle) staging area: x | mask | mask_p rows of its data
 // rows, the eps rows of its replicas (padded to 16), the (mean | logvar) rows of its data rows (16 | 16)
 // (from the third 8-row block on: the first two hold the dz exchange of the previous tile while the next one's inputs land)
-constexpr int ND_XIN = 2 * ND_RB_DW, ND_EPS = ND_XIN + 16 * 3 * 128, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + 16 * 32;
+constexpr int ND_NBMAX = 8, ND_XROW = 5 * 128;  // data rows per tile (K >= 8); floats per staged data row (below)
+constexpr int ND_XIN = 2 * ND_RB_DW, ND_EPS = ND_XIN + ND_NBMAX * ND_XROW, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + ND_NBMAX * 32;
 static_assert(ND_IN_DW <= ND_ST_DW, "tile inputs alias the staging area");
 // dz exchange [64 rows][mean 16 | logvar 16]: 32 rows per 8-row block of the staging area, in the dwords of its slots 0-15
 __host__ __device__ constexpr int nd_dzx(int row) { return (row >> 5) * ND_RB_DW + (row & 31) * 32; }
@@ -62,7 +63,7 @@ constexpr int ND_LWB = 128;  // l_w exchange: data-row groups of (K + 3) & ~3 fl
 struct NdImg {
     static constexpr int oW1 = 0, oW2 = oW1 + ND_HID * 16, oWx = oW2 + ND_HID * 64, ob1 = oWx + 256 * 64, ob2 = ob1 + ND_HID,
                          obx = ob2 + ND_HID, oWm = obx + 256, oBm = oWm + 128, total = oBm + 128, oSP = total, oSG = oSP + 128,
-                         lds_total = oSG + 128;
+                         oISP = oSG + 128, lds_total = oISP + 128;
 };
 constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_LWB + 2 * ND_WAVES * ND_NSTAT) * 4;
 static_assert(ND_LDS <= 163840, "LDS budget");
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     const float* Bm = lds + NdImg::oBm;
     float* SP = lds + NdImg::oSP;
     float* SG = lds + NdImg::oSG;
+    float* ISP = lds + NdImg::oISP;
     float* st = lds + NdImg::lds_total;
     float* lwbuf = st + ND_ST_DW;
     double* red = reinterpret_cast<double*>(lwbuf + ND_LWB);
@@ -270,7 +272,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     if (threadIdx.x < 128) {
         const float wv = lds[NdImg::oWm + threadIdx.x];
         const float e = expf(-fabsf(wv));
-        SP[threadIdx.x] = wv > 20.f ? wv : log1pf(expf(wv));
+        const float spv = wv > 20.f ? wv : log1pf(expf(wv));
+        SP[threadIdx.x] = spv;
+        ISP[threadIdx.x] = 1.f / spv;
         SG[threadIdx.x] = wv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
     }
     __syncthreads();
@@ -303,26 +307,37 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         return __builtin_bit_cast(Op, u32x4{v, v, v, v});
     };
 
-    // A tile's inputs in flight: x | mask | mask_p pieces (two 16-byte pieces per thread cover nb <= 5 data rows), the eps values of
-    // one (row, quad) and the statistics of one (data row, mean | logvar, quad) per thread
-    const bool pf = a.nb * 96 <= 2 * ND_THREADS;
-    f32x4 pfx[2], pfe, pfh;
+    // A tile's inputs in flight, per thread: x | mask | mask_p of one (data row, 4 features) item - nb * 32 items, nb <= 8 -, the eps
+    // values of one (row, quad) and the statistics of one (data row, mean | logvar, quad).  What every replica of a data row would
+    // otherwise re-derive per element is formed ONCE when the item is stored (store_inputs): with om = 1 - m,
+    //   q pass: [x | mA = m | mE = m (1 - mp) | A = -softplus(W) om | C = -softplus(W) (x m - b)]   so that logits = xm A + C
+    //   p pass: [x | mA = mp]
+    f32x4 pfx[3], pfe, pfh;
     auto tile_origin = [&](int tile, int& pass, int& b0) {
         pass = tile / a.tiles_per_pass;
         b0 = (tile - pass * a.tiles_per_pass) * a.nb;
     };
-    // (the thread id is made opaque in each of these: their address arithmetic - divisions by 96 and K included - is otherwise
+    // (the thread id is made opaque in each of these: their address arithmetic - the division by K included - is otherwise
     // hoisted out of the tile loop, and what is hoisted lives in scratch: ~20 reloads per tile)
     auto opaque_tid = [&]() {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
         return t;
     };
-    auto request_small = [&](int tile) {
+    auto request_inputs = [&](int tile) {
         int pass, b0;
         tile_origin(tile, pass, b0);
         const long m0 = ((long)pass * a.B + b0) * K;  // first decoder row (eps row) of the tile
         const int tid = opaque_tid();
+        {
+            const int it = tid < a.nb * 32 ? tid : 0;
+            const int row = it >> 5, c4 = it & 31;
+            const int br = b0 + row < a.B ? b0 + row : a.B - 1;
+            const long o = (long)br * d + 4 * c4;
+            pfx[0] = *reinterpret_cast<const f32x4*>(a.x + o);
+            pfx[1] = *reinterpret_cast<const f32x4*>(a.m + o);
+            pfx[2] = *reinterpret_cast<const f32x4*>(a.mp + o);
+        }
         {
             const int row = tid >> 2, qd = tid & 3;
             const int rb = row / K;
@@ -339,39 +354,27 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             for (int j = 0; j < 4; ++j) pfh[j] = (4 * qd + j < L) ? src[4 * qd + j] : 0.f;
         }
     };
-    auto request_inputs = [&](int tile) {
-        int pass, b0;
-        tile_origin(tile, pass, b0);
+    auto store_inputs = [&](bool qpass) {
         const int tid = opaque_tid();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * ND_THREADS;
-            const int ic = i < a.nb * 96 ? i : 0;
-            const int row = ic / 96, rem = ic - 96 * row, arr = rem >> 5, c4 = rem & 31;
-            const int br = b0 + row < a.B ? b0 + row : a.B - 1;
-            const float* src = (arr == 0 ? a.x : arr == 1 ? a.m : a.mp) + (long)br * d + 4 * c4;
-            pfx[u] = *reinterpret_cast<const f32x4*>(src);
+        if (tid < a.nb * 32) {
+            const int row = tid >> 5, c4 = tid & 31;
+            float* dst = st + ND_XIN + row * ND_XROW + 4 * c4;
+            const f32x4 x4 = pfx[0], m4 = pfx[1], p4 = pfx[2];
+            *reinterpret_cast<f32x4*>(dst) = x4;
+            if (qpass) {
+                const f32x4 sp = *reinterpret_cast<const f32x4*>(SP + 4 * c4), bj = *reinterpret_cast<const f32x4*>(Bm + 4 * c4);
+                *reinterpret_cast<f32x4*>(dst + 128) = m4;
+                *reinterpret_cast<f32x4*>(dst + 256) = m4 * (1.f - p4);
+                *reinterpret_cast<f32x4*>(dst + 384) = -sp * (1.f - m4);
+                *reinterpret_cast<f32x4*>(dst + 512) = -sp * (x4 * m4 - bj);
+            } else {
+                *reinterpret_cast<f32x4*>(dst + 128) = p4;
+            }
         }
-        request_small(tile);
-    };
-    auto store_small = [&](int b0) {
-        const int tid = opaque_tid();
         *reinterpret_cast<f32x4*>(st + ND_EPS + (tid >> 2) * 16 + 4 * (tid & 3)) = pfe;
         if (tid < a.nb * 8) *reinterpret_cast<f32x4*>(st + ND_HD + (tid >> 3) * 32 + ((tid >> 2) & 1) * 16 + 4 * (tid & 3)) = pfh;
     };
-    auto store_inputs = [&](int b0) {
-        const int tid = opaque_tid();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * ND_THREADS;
-            if (i < a.nb * 96) {
-                const int row = i / 96, rem = i - 96 * row;
-                *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + 4 * rem) = pfx[u];
-            }
-        }
-        store_small(b0);
-    };
-    if (pf && (int)blockIdx.x < a.ntiles) request_inputs(blockIdx.x);
+    if ((int)blockIdx.x < a.ntiles) request_inputs(blockIdx.x);
     NSTP(0);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
@@ -384,18 +387,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         const bool valid = rvalid && b < a.B;
         // ---------------- the tile's inputs -> LDS, once per tile (every replica of a data row reads the same x / masks / statistics);
         // they were requested from global memory while the previous tile's staging rounds ran (request_inputs below)
-        if (pf) {
-            store_inputs(b0);
-        } else {  // many data rows per tile (K < 13): more than two 16-byte pieces per thread - loaded here, latency exposed
-            request_small(tile);
-            store_small(b0);
-            for (int i = threadIdx.x; i < a.nb * 96; i += ND_THREADS) {
-                const int row = i / 96, rem = i - 96 * row, arr = rem >> 5, c4 = rem & 31;
-                const int br = b0 + row < a.B ? b0 + row : a.B - 1;
-                const float* src = (arr == 0 ? a.x : arr == 1 ? a.m : a.mp) + (long)br * d + 4 * c4;
-                *reinterpret_cast<f32x4*>(st + ND_XIN + row * 384 + arr * 128 + 4 * c4) = *reinterpret_cast<const f32x4*>(src);
-            }
-        }
+        store_inputs(qpass);
         ND_BARRIER();  // B0
         // ---------------- reparameterisation (VAE.py:2385-2389): z = mean + eps * exp(logvar / 2)   (columns >= L are staged as 0)
         f32x4 z, ehs;  // ehs = eps * exp(logvar / 2) / 2: d z / d logvar
@@ -440,15 +432,19 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- heads + bound terms of the lane's row, pass 1: sums over the features (VAE.py:2393-2396, 2405-2440).
         // The head outputs are NOT kept for pass 2 (64 registers across the exchange, beside its 64 registers of results): each
         // pass forms them tile by tile on the matrix pipe - 64 bf16 MFMAs again instead of scratch traffic.
-        const float* xin = st + ND_XIN + blc * 384 + 4 * qq;  // x at + 16 t, mask at + 128, mask_p at + 256
-        struct Elems { f32x4 xv, mv, pv, sp, bj; };
+        const float* xin = st + ND_XIN + blc * ND_XROW + 4 * qq;  // x at + 16 t; mA, mE, A, C at + 128, 256, 384, 512
+        struct Elems { f32x4 xv, mA, mE, A, C; };
         auto fetch = [&](int t) {
             Elems e;
             e.xv = *reinterpret_cast<const f32x4*>(xin + 16 * t);
-            e.mv = *reinterpret_cast<const f32x4*>(xin + 128 + 16 * t);
-            e.pv = *reinterpret_cast<const f32x4*>(xin + 256 + 16 * t);
-            e.sp = *reinterpret_cast<const f32x4*>(SP + 16 * t + 4 * qq);
-            e.bj = *reinterpret_cast<const f32x4*>(Bm + 16 * t + 4 * qq);
+            e.mA = *reinterpret_cast<const f32x4*>(xin + 128 + 16 * t);
+            if (qpass) {
+                e.mE = *reinterpret_cast<const f32x4*>(xin + 256 + 16 * t);
+                e.A = *reinterpret_cast<const f32x4*>(xin + 384 + 16 * t);
+                e.C = *reinterpret_cast<const f32x4*>(xin + 512 + 16 * t);
+            } else {
+                e.mE = e.A = e.C = zero4();
+            }
             return e;
         };
         // xm = sigmoid(.), xl = hardtanh(., -10, 0) of the lane's 4 features of tile t
@@ -465,20 +461,16 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             nd_heads<DT>(Wx, g2b, cc, qq, [&](int t) { cur = fetch(t); }, [&](int t, f32x4 a0, f32x4 a1) {
                 f32x4 xm4, xl4;
                 heads_act(t, a0, a1, xm4, xl4);
-                const f32x4 xv = cur.xv, mv = cur.mv, pv = cur.pv, sp = cur.sp, bj = cur.bj;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xm = xm4[j], xl = xl4[j];
-                    const float rr = xv[j] - xm, riv = rr * __expf(-xl);
+                    const float rr = cur.xv[j] - xm, riv = rr * __expf(-xl);
                     const float el = 0.5f * xl + 0.5f * rr * riv;
+                    sA += cur.mA[j] * el;
                     if (qpass) {
-                        sA += mv[j] * el;
-                        sE += mv[j] * (1.f - pv[j]) * el;
-                        const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
-                        const float lg = -sp[j] * (mixv - bj[j]);
-                        sN += fmaxf(lg, 0.f) - lg * mv[j] + __logf(1.f + __expf(-fabsf(lg)));
-                    } else {
-                        sA += pv[j] * el;
+                        sE += cur.mE[j] * el;
+                        const float lg = xm * cur.A[j] + cur.C[j];  // -softplus(W) (xm (1 - m) + x m - b)
+                        sN += fmaxf(lg, 0.f) - lg * cur.mA[j] + __logf(1.f + __expf(-fabsf(lg)));
                     }
                 }
             });
@@ -532,47 +524,53 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         }
         NSTP(5);
         // ---------------- pass 2: gradients w.r.t. the head PRE-activations (through Sigmoid / Hardtanh), packed as they are made
-        Op Gb[DT], E1b[DT / 2], E2b[DT / 2];
+        // (each tile's results are packed at once - 2 registers per tile and array; carried as fp32 until the partner tile of a
+        // 32-feature operand is done they are 16 more live registers in the phase that has the fewest to spare)
+        u32x2 gmh[DT], glh[DT], e1h[DT], e2h[DT];
         {
-            f32x4 gm_prev = zero4(), gl_prev = zero4(), e1_prev = zero4(), e2_prev = zero4();
             const float oe = valid ? a.oe : 0.f;
             Elems cur;
             nd_heads<DT>(Wx, g2b, cc, qq, [&](int t) { cur = fetch(t); }, [&](int t, f32x4 a0, f32x4 a1) {
                 f32x4 xm4, xl4;
                 heads_act(t, a0, a1, xm4, xl4);
-                const f32x4 xv = cur.xv, mv = cur.mv, pv = cur.pv, sp = cur.sp, bj = cur.bj;
+                const f32x4 isp = *reinterpret_cast<const f32x4*>(ISP + 16 * t + 4 * qq);
                 f32x4 gm, gl, e1 = zero4(), e2 = zero4();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xm = xm4[j], xl = xl4[j];
-                    const float rr = xv[j] - xm, riv = rr * __expf(-xl);
+                    const float rr = cur.xv[j] - xm, riv = rr * __expf(-xl);
                     const float h2 = 0.5f - 0.5f * rr * riv;  // d / d xl of the element NLL
+                    const float wA = wgt * cur.mA[j];
                     float gxm, gxl;
                     if (qpass) {
-                        const float ee = oe * mv[j] * (1.f - pv[j]);
-                        const float mixv = xm * (1.f - mv[j]) + xv[j] * mv[j];
-                        const float lg = -sp[j] * (mixv - bj[j]);
+                        const float ee = oe * cur.mE[j];
+                        const float lg = xm * cur.A[j] + cur.C[j];
                         const float el2 = __expf(-fabsf(lg)), rc = __builtin_amdgcn_rcpf(1.f + el2);
-                        const float dn = (lg >= 0.f ? rc : el2 * rc) - mv[j];
-                        gxm = wgt * (-mv[j] * riv - dn * sp[j] * (1.f - mv[j])) - ee * riv;
-                        gxl = (wgt * mv[j] + ee) * h2;
+                        const float dn = (lg >= 0.f ? rc : el2 * rc) - cur.mA[j];
                         e1[j] = wgt * dn;
-                        e2[j] = e1[j] * (mixv - bj[j]);
+                        gxm = e1[j] * cur.A[j] - (wA + ee) * riv;  // (-dn softplus(W) (1 - m) = dn A)
+                        gxl = (wA + ee) * h2;
+                        e2[j] = -e1[j] * lg * isp[j];  // e1 (xm (1 - m) + x m - b): the logit divided back by -softplus(W)
                     } else {
-                        gxm = -wgt * pv[j] * riv;
-                        gxl = wgt * pv[j] * h2;
+                        gxm = -wA * riv;
+                        gxl = wA * h2;
                     }
                     gm[j] = gxm * (xm * (1.f - xm));
                     gl[j] = (xl > -10.f && xl < 0.f) ? gxl : 0.f;
                 }
-                if (t & 1) {
-                    Gb[t >> 1] = nd_pack2(gm_prev, gm);
-                    Gb[DT / 2 + (t >> 1)] = nd_pack2(gl_prev, gl);
-                    E1b[t >> 1] = nd_pack2(e1_prev, e1);
-                    E2b[t >> 1] = nd_pack2(e2_prev, e2);
-                }
-                gm_prev = gm; gl_prev = gl; e1_prev = e1; e2_prev = e2;
+                gmh[t] = u32x2{pk_bf16(gm[0], gm[1]), pk_bf16(gm[2], gm[3])};
+                glh[t] = u32x2{pk_bf16(gl[0], gl[1]), pk_bf16(gl[2], gl[3])};
+                e1h[t] = u32x2{pk_bf16(e1[0], e1[1]), pk_bf16(e1[2], e1[3])};
+                e2h[t] = u32x2{pk_bf16(e2[0], e2[1]), pk_bf16(e2[2], e2[3])};
             });
+        }
+        Op Gb[DT], E1b[DT / 2], E2b[DT / 2];
+#pragma unroll
+        for (int kb = 0; kb < DT / 2; ++kb) {
+            Gb[kb] = __builtin_bit_cast(Op, u32x4{gmh[2 * kb][0], gmh[2 * kb][1], gmh[2 * kb + 1][0], gmh[2 * kb + 1][1]});
+            Gb[DT / 2 + kb] = __builtin_bit_cast(Op, u32x4{glh[2 * kb][0], glh[2 * kb][1], glh[2 * kb + 1][0], glh[2 * kb + 1][1]});
+            E1b[kb] = __builtin_bit_cast(Op, u32x4{e1h[2 * kb][0], e1h[2 * kb][1], e1h[2 * kb + 1][0], e1h[2 * kb + 1][1]});
+            E2b[kb] = __builtin_bit_cast(Op, u32x4{e2h[2 * kb][0], e2h[2 * kb][1], e2h[2 * kb + 1][0], e2h[2 * kb + 1][1]});
         }
         launder(cc, qq);
         VPC_CUT();
@@ -580,7 +578,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- R1a: dWx rows of the mean head, their bias, db of the missingness model
         const int fl = 16 * qq + cc;
         ND_BARRIER();  // B1': every wave is past its reads of the tile inputs, which the staged operands overwrite
-        if (pf && tile + (int)gridDim.x < a.ntiles) request_inputs(tile + gridDim.x);  // (arrive under the staging rounds)
+        if (tile + (int)gridDim.x < a.ntiles) request_inputs(tile + gridDim.x);  // (arrive under the staging rounds)
 #pragma unroll
         for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[kb]);
 #pragma unroll
@@ -831,7 +829,7 @@ __global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
     }
 }
 
-static inline bool nmdec_shape_ok(int K, int d, int L) { return d == 128 && L >= 1 && L <= 15 && K >= 4 && K <= ND_ROWS; }
+static inline bool nmdec_shape_ok(int K, int d, int L) { return d == 128 && L >= 1 && L <= 15 && K >= 8 && K <= ND_ROWS; }
 
 }  // namespace vpc
 
@@ -839,7 +837,7 @@ using namespace vpc;
 
 extern "C" {
 
-// 1 when vpc_nmdec_step covers the shape (the regularised model only; obs_dim = 128, latent_dim <= 15, 4 <= K <= 64);
+// 1 when vpc_nmdec_step covers the shape (the regularised model only; obs_dim = 128, latent_dim <= 15, 8 <= K <= 64);
 // VPC_NMDEC=0 in the environment keeps the GEMM chain (A/B runs)
 int vpc_nmdec_applicable(long B, int K, int d, int L) {
     if (B <= 0 || !nmdec_shape_ok(K, d, L)) return 0;
@@ -868,7 +866,7 @@ int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_fl
 // -(dword + 1) for values that stay fp32, INT_MIN = not in the image: the encoder),  grad_idx[i] = position of parameter i's
 // gradient inside a partial block (-1: the encoder's parameters, whose gradients the GEMM chain writes)
 int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n) {
-    if (hid != ND_HID || !nmdec_shape_ok(4, d, L)) return VPC_ERR_SHAPE;
+    if (hid != ND_HID || !nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
     if (!pack_idx || !grad_idx) return VPC_ERR_ARG;
     const int n_enc = hid * d + hid + hid * hid + hid + 2 * L * hid + 2 * L;
     const int n_dec = hid * L + hid + hid * hid + hid + 2 * d * hid + 2 * d;
