@@ -11,16 +11,15 @@
 // Workgroup: 4 waves (one per SIMD, 512 registers each), one 16-row slice of the 64-row tile per wave.  A tile holds the K replicas
 // of nb = 64 / K data rows (rows r = bl * K + k; the last 64 - nb K rows are padding: K = 20 -> 60 of 64 rows carry work); the
 // stacked passes (q rows, then p rows) are tiled separately, so a tile's pass is uniform.
-// LDS (160 256 of 163 840 bytes): one bf16 image of the three layers in the compact layout of vpc_step.hip (c_elem<KP>: W1 128 x 32,
-// W2 128 x 128, Wx 256 x 128) + fp32 biases + W, b of the missingness model and their softplus / sigmoid (110.6 KB), 24 staging
-// slots of [64 rows x 16 features] bf16 for the wgrad operands (48 KB, bf_stage layout of vpc_bf16.h), 64 floats for the K-coupling.
-// Registers: 248 gradient accumulators per lane (dWx 128, dW2 64, dW1 8, the three bias gradients 32 and dW | db of the missingness
-// model 16 - column sums come from the same staged operands as MFMAs against a constant-ones B operand), the head outputs of the
-// lane's row (64) across the log-sum-exp over K.
+// LDS (162 976 of 163 840 bytes): one bf16 image of the three layers in the compact layout of vpc_step.hip (c_elem<KP>: W1 128 x 32,
+// W2 128 x 128, Wx 256 x 128) + fp32 biases + W, b of the missingness model and their softplus / sigmoid (111 KB), 25 staging
+// slots of [64 rows x 16 features] bf16 for the wgrad operands (50 KB, bf_stage layout of vpc_bf16.h), 128 floats for the K-coupling.
+// Registers: 204 gradient accumulators per lane (dWx 128, dW2 64, dW1 8 and ONE tile for every column sum: the three bias gradients
+// and dW | db of the missingness model come from the same staged operands as MFMAs against a selector-column B operand).
 // Staging rounds per tile (write - barrier - transposed reads + MFMA - barrier), slots in brackets:
 //   R1a dWx[xm rows] = Gxm^T g2, dbx, db(miss) = e1^T 1   [0-7 | 8-15 | 16-23]
 //   R1b dWx[xl rows] = Gxl^T g2, dbx, dW(miss) = e2^T 1   [0-7 | (8-15 kept) | 16-23]
-//   R2  dW2 = dg2^T g1, db2 [0-7 | 8-15]        R3  dW1 = dg1^T z, db1 [0-7 | 8]
+//   R2  dW2 = dg2^T g1, db2 [0-7 | 8-15] (+ z -> 24)        R3  dW1 = dg1^T z, db1 [16-23 | 24]
 // and two exchanges through LDS: the rows' bound terms l_w (softmax over the K replicas of a data row sits in 2-3 different waves)
 // and dz (summed over K by one lane per (data row, latent), which also adds the analytic KL gradients).
 #include "vpc_abi_internal.h"
