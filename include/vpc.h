@@ -321,9 +321,10 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
                 long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream);
 
 /* ---- layer-fused K-fold decoder of the regularised MNAR step, plain bf16 MFMA inputs (csrc/vpc_nmdec.hip) ----------
- * Replaces, for REG_notMIWAE_v2 at obs_dim = 128 (latent_dim <= 15, 8 <= K <= 64; hidden width 128), the launches
+ * Replaces, for REG_notMIWAE_v2 and notMIWAE_myversion at obs_dim = 128 (latent_dim <= 15, 8 <= K <= 64; hidden width 128), the launches
  *   vpc_nm_sample -> 3 x vpc_linear_fwd -> vpc_nm_loss -> 3 x (vpc_linear_wgrad, vpc_linear_dgrad) -> vpc_nm_sample_bwd
- * of one training step with precision = 2 (src/models/VAE.py:2382-2396 K-fold rsample + decoder, :2398-2471 loss, and
+ * of one training step with precision = 2 (src/models/VAE.py:2382-2396 / :2753-2772 K-fold rsample + decoder, :2398-2471 /
+ * :2774-2823 loss, and
  * their autograd, src/experiment_main/train.py:115): the K replicas of a few data rows are one workgroup tile, and no
  * array of B * K rows crosses HBM.  Same mathematics, gradient weights and bf16 rounding points as that chain, except
  * that ELU' is taken from the bf16-rounded activation and the per-row terms of the missingness model's dW / db are
@@ -334,7 +335,9 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
  *                            [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]): pack_idx as
  *                            vpc_step_pack_weights_bf16 reads it (INT_MIN: not in the image - the encoder), grad_idx =
  *                            position of the parameter's gradient inside a partial block (-1: not produced here)
- *   vpc_nmdec_step           heads [2 B][ldh] = encoder (mean | logvar) of the q rows, then of the p rows; eps [2 B K][L];
+ *   vpc_nmdec_step           mask_p != NULL (REG_notMIWAE_v2): heads [2 B][ldh] = encoder (mean | logvar) of the q rows, then
+ *                            of the p rows; eps [2 B K][L] likewise.  mask_p == NULL (notMIWAE_myversion): heads [B][ldh],
+ *                            eps [2][B K][L] = the decoder's draws, then the draws of its Monte-Carlo KL; alpha is ignored.
  *                            dht [2 B][2 L] receives d loss / d heads (sum over K of dz + the analytic KL gradients);
  *                            grad (flat, n entries) receives the entries grad_idx names (fixed-order sum of the blocks);
  *                            out8 / loss_f32 / accum / state / rng_inc / B_global / alpha as vpc_nm_loss.

@@ -186,9 +186,9 @@ def test_mnar_trainer_vs_emulating_oracle(prec, kind):
     eps = torch.randn(2, B, K, L, generator=g)
     tr = nm.NMTrainer(model, precision=prec)
     tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda() if kind == "reg" else None, eps=eps.cuda(), alpha=0.5, p_missingness=50)
-    # (the regularised class in plain bf16 runs the layer-fused decoder kernel at this shape: tests/test_nmdec.py - the port then
-    # models that kernel's rounding points on the decoder side)
-    assert tr.use_nmdec == (kind == "reg" and prec == "bf16")
+    # (plain bf16 runs the layer-fused decoder kernel at this shape: tests/test_nmdec.py - the port then models that kernel's
+    # rounding points on the decoder side)
+    assert tr.use_nmdec == (prec == "bf16")
     port = NO.NMTorchPort(p, L, K, kind == "reg", linear=NO.rounded_linear(prec), fused_decoder=tr.use_nmdec)
     xd, md, mpd, ed = x.double(), m.double(), mp.double(), eps.double()
     if kind == "reg":

@@ -70,11 +70,14 @@ def _problem(d, L, K, B, seed=5):
     return p, x, m, mp, eps
 
 
-def _oracle_step(p, x, m, mp, eps, L, K, alpha, fused):
+def _oracle_step(p, x, m, mp, eps, L, K, alpha, fused, reg=True):
     pp = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    port = NO.NMTorchPort(pp, L, K, True, linear=NO.rounded_linear("bf16"), fused_decoder=fused)
+    port = NO.NMTorchPort(pp, L, K, reg, linear=NO.rounded_linear("bf16"), fused_decoder=fused)
     xd, md, mpd, ed = x.double(), m.double(), mp.double(), eps.double()
-    loss = port.reg_loss(xd, port.reg_forward(xd, md, mpd, ed[0], ed[1]), md, mpd, alpha=alpha)
+    if reg:
+        loss = port.reg_loss(xd, port.reg_forward(xd, md, mpd, ed[0], ed[1]), md, mpd, alpha=alpha)
+    else:  # notMIWAE_myversion: eps[0] = the decoder's draws, eps[1] = the draws of its Monte-Carlo KL (VAE.py:2774-2823)
+        loss = port.van_loss(xd, port.van_forward(xd, md, ed[0]), md, ed[1])
     loss.backward()
     return loss.item(), {k: v.grad.numpy() for k, v in pp.items() if v.grad is not None}
 
@@ -90,23 +93,26 @@ def test_oracle_fused_rounding_model_cpu():
     assert 0 < worst < 5e-3, worst
 
 
-def _trainer_vs_oracle(d, L, K, B, alpha, seed=5):
+def _trainer_vs_oracle(d, L, K, B, alpha, seed=5, reg=True):
     from vpc_amd import notmiwae as nm
     p, x, m, mp, eps = _problem(d, L, K, B, seed)
-    model = nm.REG_notMIWAE_v2(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1)
+    cls = nm.REG_notMIWAE_v2 if reg else nm.notMIWAE_myversion
+    model = cls(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1)
     model.load_state_dict({k: v.float() for k, v in p.items()}, strict=False)
     model = model.cuda()
     tr = nm.NMTrainer(model, precision="bf16")
-    tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda(), eps=eps.cuda(), alpha=alpha, p_missingness=50)
+    tr.step(x.cuda(), m.cuda(), mask_p=mp.cuda() if reg else None, eps=eps.cuda(), alpha=alpha, p_missingness=50)
     fused = tr.use_nmdec
-    ref, gref = _oracle_step(p, x, m, mp, eps, L, K, alpha, fused)
+    ref, gref = _oracle_step(p, x, m, mp, eps, L, K, alpha, fused, reg)
     assert abs(tr.loss_value() - ref) <= LOSS_TOL * abs(ref), (tr.loss_value(), ref)
     for k, prm in model.named_parameters():
         if k in gref:
             e = rel(prm.grad.cpu().numpy(), gref[k])
-            # (a handful of data rows: one Hardtanh gate that flips within fp32 accumulation error of the clamp moves an entry
-            # by O(1 / (B K)) of the total - the bound scales accordingly below 16 rows)
-            assert e < (GRAD_TOL if B >= 16 else 2 * GRAD_TOL), (k, e, fused)
+            # Small batches: ONE Hardtanh gate of the log-variance head that flips within fp32 accumulation error of its clamp
+            # (about one element in 1e5 sits that close) removes a whole (row, feature) term from dWxl and everything behind it -
+            # O(1 / sqrt(B K)) of a tensor's largest entry, 1e-2 at 37 x 20 rows (tools/probe_nmdec_van.py: seeds 5 and 8 flip,
+            # 6 and 7 do not).  The small cases are here for the ragged-tile paths, where a defect is an O(1) error.
+            assert e < (GRAD_TOL if B >= 100 else 10 * GRAD_TOL), (k, e, fused)
     return tr
 
 
@@ -118,6 +124,15 @@ def test_fused_decoder_vs_emulating_oracle(B, K, L, alpha):
     than one tile, many tiles per workgroup (1000 rows -> 668 tiles on 256 CUs), and the extremes of K / latent size the
     kernel accepts (K = 8: 8 data rows per tile; K = 64: one), K = 11 with 5 rows and 9 padding rows."""
     tr = _trainer_vs_oracle(128, L, K, B, alpha)
+    assert tr.use_nmdec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,L", [(128, 20, 10), (37, 20, 10), (700, 20, 10), (40, 9, 4)])
+def test_fused_decoder_unregularised_class_vs_emulating_oracle(B, K, L):
+    """notMIWAE_myversion (VAE.py:2691-2847): one pass, and the KL of every replica from a second draw z' = mean + eps_kl sd,
+    which enters the softmax weights and sends its own gradient to (mean | logvar) through the K-fold exchange."""
+    tr = _trainer_vs_oracle(128, L, K, B, 0.0, reg=False)
     assert tr.use_nmdec
 
 

@@ -52,7 +52,8 @@ constexpr int ND_NSTAT = 5;
 // rows, the eps rows of its replicas (padded to 16), the (mean | logvar) rows of its data rows (16 | 16)
 // (from the third 8-row block on: the first two hold the dz exchange of the previous tile while the next one's inputs land)
 constexpr int ND_NBMAX = 8, ND_XROW = 5 * 128;  // data rows per tile (K >= 8); floats per staged data row (below)
-constexpr int ND_XIN = 2 * ND_RB_DW, ND_EPS = ND_XIN + ND_NBMAX * ND_XROW, ND_HD = ND_EPS + ND_ROWS * 16, ND_IN_DW = ND_HD + ND_NBMAX * 32;
+constexpr int ND_XIN = 2 * ND_RB_DW, ND_EPS = ND_XIN + ND_NBMAX * ND_XROW, ND_HD = ND_EPS + ND_ROWS * 16, ND_EPK = ND_HD + ND_NBMAX * 32,
+              ND_IN_DW = ND_EPK + ND_ROWS * 16;  // (ND_EPK: the second draw of the un-regularised class's Monte-Carlo KL)
 static_assert(ND_IN_DW <= ND_ST_DW, "tile inputs alias the staging area");
 // dz exchange [64 rows][mean 16 | logvar 16]: 32 rows per 8-row block of the staging area, in the dwords of its slots 0-15
 __host__ __device__ constexpr int nd_dzx(int row) { return (row >> 5) * ND_RB_DW + (row & 31) * 32; }
@@ -84,6 +85,7 @@ struct NmdArgs {
     float* part;                                       // [blocks][ND_PART]
     double* stat_part;                                 // [blocks][ND_NSTAT]
     int B, K, d, L, nb, tiles_per_pass, ntiles;
+    int reg;                                           // 1: REG_notMIWAE_v2 (two passes); 0: notMIWAE_myversion (one pass, Monte-Carlo KL)
     float oq, op, oe, cr, kq, kp, cd;
     int dbg;
 };
@@ -241,7 +243,7 @@ __device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
 #define NSTP(i) do {} while (0)
 #endif
 
-template <int DT>
+template <int DT, bool REG>
 __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VPC_ABLATE
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     // otherwise re-derive per element is formed ONCE when the item is stored (store_inputs): with om = 1 - m,
     //   q pass: [x | mA = m | mE = m (1 - mp) | A = -softplus(W) om | C = -softplus(W) (x m - b)]   so that logits = xm A + C
     //   p pass: [x | mA = mp]
-    f32x4 pfx[3], pfe, pfh;
+    f32x4 pfx[3], pfe, pfh, pfk = zero4();
     auto tile_origin = [&](int tile, int& pass, int& b0) {
         pass = tile / a.tiles_per_pass;
         b0 = (tile - pass * a.tiles_per_pass) * a.nb;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             const long o = (long)br * d + 4 * c4;
             pfx[0] = *reinterpret_cast<const f32x4*>(a.x + o);
             pfx[1] = *reinterpret_cast<const f32x4*>(a.m + o);
-            pfx[2] = *reinterpret_cast<const f32x4*>(a.mp + o);
+            pfx[2] = REG ? *reinterpret_cast<const f32x4*>(a.mp + o) : zero4();
         }
         {
             const int row = tid >> 2, qd = tid & 3;
@@ -343,6 +345,11 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             const bool rok = row < a.nb * K && b0 + rb < a.B;
 #pragma unroll
             for (int j = 0; j < 4; ++j) pfe[j] = (rok && 4 * qd + j < L) ? a.eps[(m0 + row) * L + 4 * qd + j] : 0.f;
+            if (!REG) {  // eps_kl: the second [B K][L] array behind the first
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pfk[j] = (rok && 4 * qd + j < L) ? a.eps[((long)a.B * K + m0 + row) * L + 4 * qd + j] : 0.f;
+            }
         }
         pfh = zero4();
         if (tid < a.nb * 8) {
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             }
         }
         *reinterpret_cast<f32x4*>(st + ND_EPS + (tid >> 2) * 16 + 4 * (tid & 3)) = pfe;
+        if (!REG) *reinterpret_cast<f32x4*>(st + ND_EPK + (tid >> 2) * 16 + 4 * (tid & 3)) = pfk;
         if (tid < a.nb * 8) *reinterpret_cast<f32x4*>(st + ND_HD + (tid >> 3) * 32 + ((tid >> 2) & 1) * 16 + 4 * (tid & 3)) = pfh;
     };
     if ((int)blockIdx.x < a.ntiles) request_inputs(blockIdx.x);
@@ -390,17 +398,27 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         ND_BARRIER();  // B0
         // ---------------- reparameterisation (VAE.py:2385-2389): z = mean + eps * exp(logvar / 2)   (columns >= L are staged as 0)
         f32x4 z, ehs;  // ehs = eps * exp(logvar / 2) / 2: d z / d logvar
+        f32x4 zk = zero4(), hk = zero4();  // un-regularised class: z' of the KL draw and eps_kl sd / 2
+        float klmc = 0.f;
         {
             const f32x4 mu = *reinterpret_cast<const f32x4*>(st + ND_HD + blc * 32 + 4 * qq);
             const f32x4 lv = *reinterpret_cast<const f32x4*>(st + ND_HD + blc * 32 + 16 + 4 * qq);
             const f32x4 e = *reinterpret_cast<const f32x4*>(st + ND_EPS + r * 16 + 4 * qq);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float esd = e[j] * __expf(0.5f * lv[j]);
+                const float sd = __expf(0.5f * lv[j]);
+                const float esd = e[j] * sd;
                 z[j] = mu[j] + esd;
                 ehs[j] = 0.5f * esd;
+                if (!REG) {  // notMIWAE_myversion: KL from a second draw z' = mean + eps_kl sd (VAE.py:2786-2791), per replica
+                    const float ek = *(st + ND_EPK + r * 16 + 4 * qq + j);
+                    zk[j] = mu[j] + ek * sd;
+                    hk[j] = 0.5f * ek * sd;
+                    klmc += -0.5f * ek * ek - 0.5f * lv[j] + 0.5f * zk[j] * zk[j];
+                }
             }
         }
+        if (!REG) { klmc += __shfl_xor(klmc, 16, 64); klmc += __shfl_xor(klmc, 32, 64); }
         const Op zb = nd_pack2(z, zero4());
         NSTP(1);
         // ---------------- decoder forward
@@ -487,7 +505,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             sN += __shfl_xor(sN, 16, 64); sN += __shfl_xor(sN, 32, 64);
         }
         const float RE = sA + a.cd;
-        const float lw = RE + sN;  // (the analytic KL of the data row is the same for its K replicas: it cancels in the softmax)
+        // (regularised class: the analytic KL of the data row is the same for its K replicas and cancels in the softmax; the
+        // Monte-Carlo KL of the other class differs per replica)
+        const float lw = RE + sN + klmc;
         if (qq == 0 && rvalid) lwbuf[bl * KP4 + k] = lw;
         NSTP(4);
         ND_BARRIER();  // B1
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             wgt = valid ? (qpass ? a.oq : a.op) * __expf(lw - lse) : 0.f;
             if (valid && qq == 0) {
                 if (k == 0) S[qpass ? 0 : 1] += lse;
-                if (qpass) { S[2] += sE + a.cd; S[4] += RE; }
+                if (qpass) { if (REG) S[2] += sE + a.cd; S[4] += RE; }
             }
         }
         NSTP(5);
@@ -686,8 +706,15 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // the dz exchange lives in the dwords of slots 0-15 (all reads of R2 are behind B8): no barrier in front of the writes either
         {
             float* dzx = st + nd_dzx(r);
-            const f32x4 dm = valid ? dz : zero4();
-            const f32x4 dl = valid ? dz * ehs : zero4();
+            f32x4 dm = valid ? dz : zero4();
+            f32x4 dl = valid ? dz * ehs : zero4();
+            if (!REG) {  // d KL_mc / d (mean | logvar) of the replica, weighted like the rest of its row (VAE.py:2786-2791)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dm[j] += wgt * zk[j];
+                    dl[j] += wgt * (zk[j] * hk[j] - 0.5f);
+                }
+            }
             *reinterpret_cast<f32x4*>(dzx + 4 * qq) = dm;
             *reinterpret_cast<f32x4*>(dzx + 16 + 4 * qq) = dl;
         }
@@ -700,6 +727,10 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             float sm = 0.f;
             for (int kk = part; kk < K; kk += 2) sm += st[nd_dzx(ebl * K + kk) + col];
             sm += __shfl_xor(sm, 32, 64);
+            if (!REG) {  // un-regularised class: no analytic terms - the Monte-Carlo KL's gradients came through the exchange
+                if (lane < 32 && eb < a.B && l < L) a.dht[(long)eb * (2 * L) + (col < 16 ? l : L + l)] = sm;
+                continue;
+            }
             if (lane < 32 && eb < a.B && l < L) {
                 const float* hq = a.heads + (long)eb * a.ldh;
                 const float* hp = a.heads + ((long)a.B + eb) * a.ldh;
@@ -779,7 +810,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
 struct NmdFinArgs {
     const float* part; const double* stat_part; int n_blocks;
     const int* grad_idx; float* grad; int n;   // grad[i] = sum over blocks of part[block][grad_idx[i]] where grad_idx[i] >= 0
-    int B, K, L; double alpha, inv_B;
+    int B, K, L, reg; double alpha, inv_B;
     double* out; float* loss_f32; float* accum; long long* state; long long rng_inc;
 };
 __global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
@@ -815,10 +846,10 @@ __global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
     if (threadIdx.x == 0) {
         const double logK = log((double)a.K);
         const double loss_q = red[0][0] * a.inv_B - logK * (a.B * a.inv_B);
-        const double loss_p = red[0][1] * a.inv_B - logK * (a.B * a.inv_B);
+        const double loss_p = a.reg ? red[0][1] * a.inv_B - logK * (a.B * a.inv_B) : 0.0;
         const double nll_e = red[0][2] * a.inv_B / a.K;
         const double kl_reg = red[0][3] * a.inv_B / a.L;
-        a.out[0] = loss_q + a.alpha * (kl_reg - loss_q + loss_p + nll_e);
+        a.out[0] = a.reg ? loss_q + a.alpha * (kl_reg - loss_q + loss_p + nll_e) : loss_q;
         a.out[1] = loss_q; a.out[2] = loss_p; a.out[3] = kl_reg; a.out[4] = nll_e;
         a.out[5] = red[0][4] * a.inv_B / a.K;
         a.out[6] = red[0][0]; a.out[7] = red[0][1];
@@ -847,7 +878,7 @@ int vpc_nmdec_applicable(long B, int K, int d, int L) {
 }
 
 // sizes the caller allocates: the image (floats), one partial block (floats) and the most workgroups a launch uses
-int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks) {
+int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks) {  // (max_blocks: of the two-pass form)
     if (B <= 0 || !nmdec_shape_ok(K, d, L)) return VPC_ERR_SHAPE;
     if (img_floats) *img_floats = NdImg::total;
     if (part_floats) *part_floats = ND_PART;
@@ -920,19 +951,21 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
                    const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, float* grad, int n,
                    double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
                    int K, int d, int L, double alpha, void* stream) {
-    if (!img || !x || !mask || !mask_p || !heads || !eps || !dht || !part || !stat_part || !grad_idx || !grad || !out8)
-        return VPC_ERR_ARG;
+    if (!img || !x || !mask || !heads || !eps || !dht || !part || !stat_part || !grad_idx || !grad || !out8) return VPC_ERR_ARG;
+    const int reg = mask_p != nullptr;  // NULL: notMIWAE_myversion (one pass; eps = [B K][L] draws, then the [B K][L] draws of its KL)
+    if (!reg) alpha = 0.0;
     if (B <= 0 || B_global < B || ldh < 2 * L || B * (long)K > 0x3fffff00L) return VPC_ERR_ARG;
     if (!nmdec_shape_ok(K, d, L)) return VPC_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(mask_p) |
-         reinterpret_cast<uintptr_t>(img)) & 15)
+         reinterpret_cast<uintptr_t>(img)) & 15)  // (a NULL mask_p is aligned)
         return VPC_ERR_ARG;
     NmdArgs a{};
     a.img = img; a.x = x; a.m = mask; a.mp = mask_p; a.heads = heads; a.ldh = ldh; a.eps = eps; a.dht = dht; a.part = part;
     a.stat_part = stat_part; a.B = (int)B; a.K = K; a.d = d; a.L = L;
     a.nb = ND_ROWS / K;
     a.tiles_per_pass = (int)((B + a.nb - 1) / a.nb);
-    a.ntiles = 2 * a.tiles_per_pass;
+    a.reg = reg;
+    a.ntiles = (reg ? 2 : 1) * a.tiles_per_pass;
     const double Bg = (double)B_global;
     a.oq = (float)((1.0 - alpha) / Bg); a.op = (float)(alpha / Bg); a.oe = (float)(alpha / (Bg * K));
     a.cr = (float)(alpha / (Bg * L)); a.kq = a.oq; a.kp = a.op;
@@ -943,12 +976,17 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
     const int cap = num_cus();
     const int blocks = a.ntiles < cap ? a.ntiles : cap;
     hipStream_t st = (hipStream_t)stream;
-    if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8>), ND_LDS)) return VPC_ERR_HIP;
-    hipLaunchKernelGGL((nmdec_kernel<8>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
+    if (reg) {
+        if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8, true>), ND_LDS)) return VPC_ERR_HIP;
+        hipLaunchKernelGGL((nmdec_kernel<8, true>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
+    } else {
+        if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8, false>), ND_LDS)) return VPC_ERR_HIP;
+        hipLaunchKernelGGL((nmdec_kernel<8, false>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
+    }
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
     NmdFinArgs f{};
     f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.grad_idx = grad_idx; f.grad = grad; f.n = n;
-    f.B = (int)B; f.K = K; f.L = L; f.alpha = alpha; f.inv_B = 1.0 / Bg;
+    f.B = (int)B; f.K = K; f.L = L; f.reg = reg; f.alpha = alpha; f.inv_B = 1.0 / Bg;
     f.out = out8; f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
     hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(1 + (n + 255) / 256), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;

@@ -596,8 +596,8 @@ class NMTrainer:
         self.xin, self.mask_p = e(R, d), e(B, d)
         self.h1, self.h2, self.heads = e(R, HID), e(R, HID), e(R, 2 * Ld)
         self.eps = e(2, B, K, Ld)  # reg: eps_q, eps_p; vanilla: eps (sampling), eps_kl (MC KL)
-        # layer-fused decoder (plain bf16, regularised model, obs_dim 128): nothing of B * K rows is materialised
-        self.use_nmdec = bool(self.reg and self.prec == 2 and nmdec_applicable(B, K, d, Ld))
+        # layer-fused decoder (plain bf16, obs_dim 128, both model classes): nothing of B * K rows is materialised
+        self.use_nmdec = bool(self.prec == 2 and nmdec_applicable(B, K, d, Ld))
         Mg = 0 if self.use_nmdec else M  # rows of the GEMM chain's decoder-side workspaces
         self.z, self.g1, self.g2, self.Y = e(Mg, Ld), e(Mg, HID), e(Mg, HID), e(Mg, 2 * d)
         self.G, self.gheads, self.dht = e(Mg, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
