@@ -339,15 +339,17 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
  *                            of the p rows; eps [2 B K][L] likewise.  mask_p == NULL (notMIWAE_myversion): heads [B][ldh],
  *                            eps [2][B K][L] = the decoder's draws, then the draws of its Monte-Carlo KL; alpha is ignored.
  *                            dht [2 B][2 L] receives d loss / d heads (sum over K of dz + the analytic KL gradients);
- *                            grad (flat, n entries) receives the entries grad_idx names (fixed-order sum of the blocks);
+ *                            grad (flat, n entries) receives the entries grad_idx names (fixed-order sum of the blocks; inv_idx,
+ *                            optional device table [part_floats]: parameter index of a block position or -1 - the blocks are
+ *                            then read in layout order, 16 bytes per lane);
  *                            out8 / loss_f32 / accum / state / rng_inc / B_global / alpha as vpc_nm_loss.
  *                            part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (caller-owned). */
 int vpc_nmdec_applicable(long B, int K, int d, int L);
 int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks);
 int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n);
 int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
-                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, float* grad, int n,
-                   double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
+                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx,
+                   float* grad, int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
                    int K, int d, int L, double alpha, void* stream);
 
 /* ---- PNP / EDDI encoder front-end (Reg_EDDI / vanilla_EDDI, src/models/VAE.py:719-733, 903-917) ----------

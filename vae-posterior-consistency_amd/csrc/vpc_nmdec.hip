@@ -810,10 +810,38 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
 struct NmdFinArgs {
     const float* part; const double* stat_part; int n_blocks;
     const int* grad_idx; float* grad; int n;   // grad[i] = sum over blocks of part[block][grad_idx[i]] where grad_idx[i] >= 0
+    const int* inv_idx;                        // optional [ND_PART]: parameter of a block position (-1: none) - the blocks are then
+                                               // read in layout order, 16 bytes per lane (reduce_body_v2 of vpc_misc.hip)
     int B, K, L, reg; double alpha, inv_B;
     double* out; float* loss_f32; float* accum; long long* state; long long rng_inc;
 };
 __global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
+    if (blockIdx.x > 0 && a.inv_idx) {
+        // 8 positions of 4 floats x 32 block groups per workgroup: every thread has its loads in flight at once, a wave reads full
+        // 128-byte lines; summation order: blocks g, g + 32, ... per group, then groups 0 .. 31 (fixed: reproducible)
+        __shared__ f32x4 sh[32][8];
+        const int blk = blockIdx.x - 1, pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
+        const int p4 = blk * 8 + pi;
+        f32x4 s0 = zero4();
+        if (p4 < ND_PART / 4) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.part) + p4;
+#pragma unroll 4
+            for (int b = bg; b < a.n_blocks; b += 32) s0 += p[(long)b * (ND_PART / 4)];
+        }
+        sh[bg][pi] = s0;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int pos = threadIdx.x >> 2, k = threadIdx.x & 3;
+            if (blk * 8 + pos < ND_PART / 4) {
+                float t = sh[0][pos][k];
+#pragma unroll
+                for (int g = 1; g < 32; ++g) t += sh[g][pos][k];
+                const int id = a.inv_idx[4 * (blk * 8 + pos) + k];
+                if (id >= 0) a.grad[id] = t;
+            }
+        }
+        return;
+    }
     if (blockIdx.x > 0) {
         const int i = (blockIdx.x - 1) * 256 + threadIdx.x;
         if (i >= a.n) return;
@@ -945,11 +973,11 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
 // The fused decoder + loss + decoder backward of one regularised MNAR step (two launches: the tile kernel and the fixed-order
 // reduction of its partial blocks).  heads [2 B][ldh] = the encoder's (mean | logvar) rows of the q pass, then of the p pass;
 // eps [2 B K][L]; dht [2 B][2 L] receives the gradient w.r.t. heads (K-fold sum of dz + the analytic KL gradients);
-// grad (the model's flat gradient buffer, n entries) receives the entries grad_idx names; out8 / loss_f32 / accum / state as
-// vpc_nm_loss.  part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (vpc_nmdec_layout).
+// grad (the model's flat gradient buffer, n entries) receives the entries grad_idx names (inv_idx, optional: the inverse table
+// [part_floats] position -> parameter or -1, for the layout-order reduction); out8 / loss_f32 / accum / state as vpc_nm_loss.  part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (vpc_nmdec_layout).
 int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
-                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, float* grad, int n,
-                   double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
+                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx, float* grad,
+                   int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
                    int K, int d, int L, double alpha, void* stream) {
     if (!img || !x || !mask || !heads || !eps || !dht || !part || !stat_part || !grad_idx || !grad || !out8) return VPC_ERR_ARG;
     const int reg = mask_p != nullptr;  // NULL: notMIWAE_myversion (one pass; eps = [B K][L] draws, then the [B K][L] draws of its KL)
@@ -985,10 +1013,11 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
     }
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
     NmdFinArgs f{};
-    f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.grad_idx = grad_idx; f.grad = grad; f.n = n;
+    f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.grad_idx = grad_idx; f.inv_idx = inv_idx; f.grad = grad; f.n = n;
     f.B = (int)B; f.K = K; f.L = L; f.reg = reg; f.alpha = alpha; f.inv_B = 1.0 / Bg;
     f.out = out8; f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
-    hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(1 + (n + 255) / 256), dim3(256), 0, st, f);
+    const int fin_grid = 1 + (inv_idx ? (ND_PART / 4 + 7) / 8 : (n + 255) / 256);
+    hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(fin_grid), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

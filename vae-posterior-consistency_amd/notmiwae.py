@@ -124,13 +124,19 @@ def nmdec_tables(model, device):
     pidx, gidx = np.empty(n, np.int32), np.empty(n, np.int32)
     check(lib().vpc_nmdec_build_indices(d, Ld, HID, pidx.ctypes.data_as(L.P), gidx.ctypes.data_as(L.P), n),
           "vpc_nmdec_build_indices")
-    return torch.from_numpy(pidx).to(device), torch.from_numpy(gidx).to(device)
+    # inverse table for the layout-order reduction of the partial blocks: parameter index of a block position, -1 where none
+    npart = C.c_long()
+    check(lib().vpc_nmdec_layout(1, 8, d, Ld, None, C.byref(npart), None), "vpc_nmdec_layout")
+    inv = np.full(npart.value, -1, np.int32)
+    own = np.nonzero(gidx >= 0)[0]
+    inv[gidx[own]] = own.astype(np.int32)
+    return torch.from_numpy(pidx).to(device), torch.from_numpy(gidx).to(device), torch.from_numpy(inv).to(device)
 
 
-def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, grad, out8, loss_f32, accum, B, B_global, K, d,
+def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, inv, grad, out8, loss_f32, accum, B, B_global, K, d,
                Ld, alpha, state=None, rng_inc=0):
     check(lib().vpc_nmdec_step(ptr(img), ptr(x), ptr(mask), ptr(mask_p), ptr(heads), 2 * Ld, ptr(eps), ptr(dht),
-                               ptr(part), ptr(stat), ptr(gidx), ptr(grad), grad.numel(), ptr(out8), ptr(loss_f32),
+                               ptr(part), ptr(stat), ptr(gidx), ptr(inv), ptr(grad), grad.numel(), ptr(out8), ptr(loss_f32),
                                ptr(accum), ptr(state), int(rng_inc), B, B_global, K, d, Ld, float(alpha), stream_ptr()),
           "vpc_nmdec_step")
 
@@ -696,11 +702,11 @@ class NMTrainer:
         if self.use_nmdec:
             # K-fold rsample, decoder, loss, decoder backward and the K-fold sum of dz in ONE kernel (csrc/vpc_nmdec.hip): the
             # decoder / missingness-model gradients land in self.grad, d loss / d heads in self.dht
-            pidx, gidx = self._nd_tables
+            pidx, gidx, ginv = self._nd_tables
             from .ops import step_pack_weights_bf16
             t("pack", step_pack_weights_bf16, m._flat, pidx, self.nd_img)
             t("dec_fused", nmdec_step, self.nd_img, xf, mf, mp, self.heads, self.eps, self.dht, self.nd_part, self.nd_stat,
-              gidx, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
+              gidx, ginv, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
               _state, rng_inc)
         else:
             self._step_decoder_gemms(xf, mf, mp, B, Bg, alpha, _state, rng_inc, t, v, wgrad)
