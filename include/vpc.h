@@ -327,8 +327,8 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
  * :2774-2823 loss, and
  * their autograd, src/experiment_main/train.py:115): the K replicas of a few data rows are one workgroup tile, and no
  * array of B * K rows crosses HBM.  Same mathematics, gradient weights and bf16 rounding points as that chain, except
- * that ELU' is taken from the bf16-rounded activation and the per-row terms of the missingness model's dW / db are
- * rounded to bf16 before their sum over rows (tests/test_nmdec.py; oracle/notmiwae_oracle.py mirrors both).
+ * that ELU' is taken from the bf16-rounded activation and the bias gradients are column sums of the bf16-rounded dY
+ * (tests/test_nmdec.py; oracle/notmiwae_oracle.py mirrors both).
  *   vpc_nmdec_applicable     1 when vpc_nmdec_step covers the shape (VPC_NMDEC=0 in the environment: never)
  *   vpc_nmdec_layout         floats of the weight image, floats of one partial block, most workgroups of a launch
  *   vpc_nmdec_build_indices  HOST tables over the model's flat parameter buffer (n entries, order

@@ -132,31 +132,12 @@ class _EluRoundedGate(torch.autograd.Function):
         return dy * torch.where(yr > 0, torch.ones_like(yr), yr + 1)
 
 
-class _MissLogitsRounded(torch.autograd.Function):
-    """logits = -softplus(W) (mixed - b) of the self-masking model (VAE.py:2424-2427) with the row terms of dW / db rounded to
-    bf16 before they are summed over the rows - the layer-fused decoder kernel sums them as MFMAs of staged bf16 operands."""
-
-    @staticmethod
-    def forward(ctx, W, b, mixed):
-        ctx.save_for_backward(W, b, mixed)
-        return -F.softplus(W) * (mixed - b)
-
-    @staticmethod
-    def backward(ctx, g):
-        W, b, mixed = ctx.saved_tensors
-        sp, sg = F.softplus(W), torch.sigmoid(W)
-        red = tuple(range(g.dim() - 1))
-        gW = -sg * _bf16_t(g * (mixed - b)).sum(red).reshape(W.shape)
-        gb = sp * _bf16_t(g).sum(red).reshape(b.shape)
-        return gW, gb, -sp * g
-
-
 class NMTorchPort:
     """Functional restatement over a dict of tensors (keys NM_KEYS).  ``regularised`` selects REG_notMIWAE_v2.
     ``linear``: the affine layer (default F.linear; `rounded_linear("bf16")` models the bf16 GEMM kernels).
     ``fused_decoder``: model the rounding points of the layer-fused decoder kernel (csrc/vpc_nmdec.hip) on the decoder side:
-    bias gradients from the bf16-rounded dY, ELU' from the bf16-rounded activation, bf16 row terms of the missingness
-    model's dW / db (the encoder keeps `linear`: it stays on the GEMM kernels)."""
+    bias gradients from the bf16-rounded dY, ELU' from the bf16-rounded activation (the missingness model's dW / db are fp32
+    row sums there as everywhere; the encoder keeps `linear`: it stays on the GEMM kernels)."""
 
     def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool, linear=None, fused_decoder=False):
         self.p = params
@@ -195,10 +176,7 @@ class NMTorchPort:
 
     def _logp_s(self, x3, m3, xm):  # VAE.py:2413-2432 'selfmasking_known'
         mixed = xm * (1 - m3) + x3 * m3
-        if self.fused_decoder:
-            logits = _MissLogitsRounded.apply(self.p["W"], self.p["b"], mixed)
-        else:
-            logits = -F.softplus(self.p["W"]) * (mixed - self.p["b"])
+        logits = -F.softplus(self.p["W"]) * (mixed - self.p["b"])
         return torch.sum(m3 * logits - F.softplus(logits), 2)  # Bernoulli(logits).log_prob(m)
 
     def reg_forward(self, x, mask, mask_p, eps_q, eps_p):  # VAE.py:2500-2505 (p outputs first)

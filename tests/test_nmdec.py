@@ -91,6 +91,7 @@ def test_oracle_fused_rounding_model_cpu():
     assert l0 == l1
     worst = max(rel(g1[k], g0[k]) for k in g0)
     assert 0 < worst < 5e-3, worst
+    assert rel(g1["W"], g0["W"]) < 5e-3 and rel(g1["b"], g0["b"]) < 5e-3
 
 
 def _trainer_vs_oracle(d, L, K, B, alpha, seed=5, reg=True):

@@ -67,12 +67,12 @@ struct NdImg {
 };
 constexpr int ND_LDS = (NdImg::lds_total + ND_ST_DW + ND_LWB + 2 * ND_WAVES * ND_NSTAT) * 4;
 static_assert(ND_LDS <= 163840, "LDS budget");
-// partial block: [204 accumulator registers][256 threads]
-constexpr int ND_REGS = 204, ND_PART = ND_REGS * ND_THREADS;
+// partial block: [204 accumulator registers + 4 of the missingness model][256 threads]
+constexpr int ND_REGS = 208, ND_PART = ND_REGS * ND_THREADS;
 constexpr int R_X = 0, R_2 = 128, R_1 = 192, R_B = 200;
-// columns of a wave's ONE bias accumulator tile (accb, see the kernel): bx of its four head tiles, b2, b1 of its two hidden tiles
-// each, db | dW of the missingness model for its two feature tiles
-constexpr int NB_BX = 0, NB_B2 = 4, NB_B1 = 6, NB_WB = 8;
+// columns of a wave's ONE bias accumulator tile (accb, see the kernel): bx of its four head tiles, b2, b1 of its two hidden tiles each
+constexpr int NB_BX = 0, NB_B2 = 4, NB_B1 = 6;
+constexpr int R_WB = 204;  // 4 more registers of wave 0's threads: dW | db of the missingness model, summed over the waves
 
 typedef bf16x8 Op;
 
@@ -235,6 +235,15 @@ __device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
                  a2 > 0.f ? dy[2] : dy[2] * (a2 + 1.f), a3 > 0.f ? dy[3] : dy[3] * (a3 + 1.f)};
 }
 
+// sum over the 16 lanes of a DPP row (the 16 batch rows of a lane group): every lane gets it (first half of wave_sum_dpp)
+__device__ __forceinline__ float row_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+
 #ifdef VPC_ABLATE
 #define ND_BARRIER() do { if (!(a.dbg & 2)) lds_barrier(); } while (0)
 #define NSTP(i) VPC_STAMP(i)
@@ -292,6 +301,10 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     // the tile's 16 column sums into column n of ONE accumulator tile - 4 registers for the wave's twelve such tiles instead of
     // 4 each (with 48 more accumulators the kernel needs more than 512 registers and hipcc evicts accumulators to scratch).
     f32x4 accx[4][8], acc2[2][8], acc1[2], accb = zero4();
+    // dW | db of the missingness model: row sums of e1 = w dn and e2 = e1 (mix - b) in fp32.  Value e = 4 t + j of a lane group (tile
+    // t, register j: feature 16 t + 4 q + j) is summed over the group's 16 rows by four DPP adds and kept by lane c = e & 15 in
+    // accumulator e >> 4: two registers per lane and array for the 32 values.
+    float acc_e1[2] = {0.f, 0.f}, acc_e2[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -545,7 +558,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- pass 2: gradients w.r.t. the head PRE-activations (through Sigmoid / Hardtanh), packed as they are made
         // (each tile's results are packed at once - 2 registers per tile and array; carried as fp32 until the partner tile of a
         // 32-feature operand is done they are 16 more live registers in the phase that has the fewest to spare)
-        u32x2 gmh[DT], glh[DT], e1h[DT], e2h[DT];
+        u32x2 gmh[DT], glh[DT];
         {
             const float oe = valid ? a.oe : 0.f;
             Elems cur;
@@ -579,17 +592,21 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 }
                 gmh[t] = u32x2{pk_bf16(gm[0], gm[1]), pk_bf16(gm[2], gm[3])};
                 glh[t] = u32x2{pk_bf16(gl[0], gl[1]), pk_bf16(gl[2], gl[3])};
-                e1h[t] = u32x2{pk_bf16(e1[0], e1[1]), pk_bf16(e1[2], e1[3])};
-                e2h[t] = u32x2{pk_bf16(e2[0], e2[1]), pk_bf16(e2[2], e2[3])};
+                if (qpass) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * t + j;
+                        const float s1 = row_sum_dpp(e1[j]), s2 = row_sum_dpp(e2[j]);
+                        if (cc == (e & 15)) { acc_e1[e >> 4] += s1; acc_e2[e >> 4] += s2; }
+                    }
+                }
             });
         }
-        Op Gb[DT], E1b[DT / 2], E2b[DT / 2];
+        Op Gb[DT];
 #pragma unroll
         for (int kb = 0; kb < DT / 2; ++kb) {
             Gb[kb] = __builtin_bit_cast(Op, u32x4{gmh[2 * kb][0], gmh[2 * kb][1], gmh[2 * kb + 1][0], gmh[2 * kb + 1][1]});
             Gb[DT / 2 + kb] = __builtin_bit_cast(Op, u32x4{glh[2 * kb][0], glh[2 * kb][1], glh[2 * kb + 1][0], glh[2 * kb + 1][1]});
-            E1b[kb] = __builtin_bit_cast(Op, u32x4{e1h[2 * kb][0], e1h[2 * kb][1], e1h[2 * kb + 1][0], e1h[2 * kb + 1][1]});
-            E2b[kb] = __builtin_bit_cast(Op, u32x4{e2h[2 * kb][0], e2h[2 * kb][1], e2h[2 * kb + 1][0], e2h[2 * kb + 1][1]});
         }
         launder(cc, qq);
         VPC_CUT();
@@ -602,10 +619,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[kb]);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) nd_st_op(st, r, 8, kb, qq, g2b[kb]);
-        if (qpass) {
-#pragma unroll
-            for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E1b[kb]);
-        }
         ND_BARRIER();  // B2
         auto round_x = [&](auto half_c) {
             constexpr int half = decltype(half_c)::value;  // owner: wave w -> head tiles w and w + 4 of this half (DT = 8: both exist)
@@ -623,13 +636,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     for (int nt = 0; nt < 8; ++nt) accx[ai][nt] = VPC_MFMA_BF(fa, fb[nt], accx[ai][nt]);
                     accb = VPC_MFMA_BF(fa, sel_col(NB_BX + ai, cc), accb);
                 }
-                if (qpass && (DT == 8 || 2 * w < DT)) {  // column sums of e1 (half 0) / e2 (half 1): tiles 2 w, 2 w + 1
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const Op fe = nd_st_frag(st, 16 + 2 * w + i, kb, fl);
-                        accb = VPC_MFMA_BF(fe, sel_col(NB_WB + 2 * half + i, cc), accb);
-                    }
-                }
             }
         };
         round_x(std::integral_constant<int, 0>{});
@@ -637,10 +643,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // ---------------- R1b: the log-variance head (g2 stays in slots 8-15)
 #pragma unroll
         for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 0, kb, qq, Gb[DT / 2 + kb]);
-        if (qpass) {
-#pragma unroll
-            for (int kb = 0; kb < DT / 2; ++kb) nd_st_op(st, r, 16, kb, qq, E2b[kb]);
-        }
         ND_BARRIER();  // B4
         round_x(std::integral_constant<int, 1>{});
         launder(cc, qq);
@@ -774,17 +776,28 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) part[(R_1 + 4 * i + j) * ND_THREADS] = acc1[i][j];
-    // the bias tile: lane column c = NB_* + index, rows 4 q + j = the feature inside its tile.  Missingness model (columns
-    // NB_WB + i2: i2 < 2 sums of e1, i2 >= 2 sums of e2 over the rows, features 16 (2 w + (i2 & 1)) + 4 q + j):
-    // db = softplus(W) * sum e1, dW = -sigmoid(W) * sum e2   (VAE.py:2424-2431 through autograd)
+    // the bias tile: lane column c = NB_* + index, rows 4 q + j = the feature inside its tile
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v = accb[j];
-        if (c >= NB_WB && c < NB_WB + 4) {
-            const int i2 = c - NB_WB, f = (16 * (2 * w + (i2 & 1)) + 4 * q + j) & 127;
-            v *= (i2 < 2) ? SP[f] : -SG[f];
+    for (int j = 0; j < 4; ++j) part[(R_B + j) * ND_THREADS] = accb[j];
+    // missingness model: lane (c, q), register g holds the row sums of feature f = 16 ((c + 16 g) >> 2) + 4 q + ((c + 16 g) & 3) over
+    // the wave's rows; the four waves are added in wave order by wave 0 (through the idle staging area), then
+    // db = softplus(W) * sum e1, dW = -sigmoid(W) * sum e2   (VAE.py:2424-2431 through autograd)
+    __syncthreads();
+    {
+        float* xw = st;  // [4 waves][64 lanes][4]
+        *reinterpret_cast<f32x4*>(xw + (w * 64 + lane) * 4) = f32x4{acc_e1[0], acc_e1[1], acc_e2[0], acc_e2[1]};
+        __syncthreads();
+        if (w == 0) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(xw + lane * 4);
+#pragma unroll
+            for (int ww = 1; ww < ND_WAVES; ++ww) t += *reinterpret_cast<const f32x4*>(xw + (ww * 64 + lane) * 4);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int e = c + 16 * g, f = (16 * (e >> 2) + 4 * q + (e & 3)) & 127;
+                part[(R_WB + g) * ND_THREADS] = SP[f] * t[g];           // db
+                part[(R_WB + 2 + g) * ND_THREADS] = -SG[f] * t[2 + g];  // dW
+            }
         }
-        part[(R_B + j) * ND_THREADS] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -932,13 +945,13 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
     for (int i = 0; i < n; ++i) { pack_idx[i] = INT_MIN; grad_idx[i] = -1; }
     // position inside a partial block of accumulator register `reg` of thread (wave w, lane 16 q + c)
     auto pos = [](int reg, int w, int q, int c) { return reg * ND_THREADS + 64 * w + 16 * q + c; };
-    // missingness model: columns NB_WB + i (db) / NB_WB + 2 + i (dW) of wave w's bias tile: features 16 (2 w + i) + 4 q + j
+    // missingness model: wave 0's lane (c, q), register R_WB + g (db) / R_WB + 2 + g (dW): feature 16 ((c + 16 g) >> 2) + 4 q + ((c + 16 g) & 3)
     for (int f = 0; f < d; ++f) {
-        const int t = f >> 4, w = t >> 1, i = t & 1, q = (f >> 2) & 3, j = f & 3;
+        const int t = f >> 4, q = (f >> 2) & 3, j = f & 3, e = 4 * t + j, c = e & 15, g = e >> 4;
         pack_idx[f] = -(NdImg::oWm + f + 1);
         pack_idx[d + f] = -(NdImg::oBm + f + 1);
-        grad_idx[f] = pos(R_B + j, w, q, NB_WB + 2 + i);
-        grad_idx[d + f] = pos(R_B + j, w, q, NB_WB + i);
+        grad_idx[f] = pos(R_WB + 2 + g, 0, q, c);
+        grad_idx[d + f] = pos(R_WB + g, 0, q, c);
     }
     int o = 2 * d + n_enc;
     const int oWd1 = o, obd1 = oWd1 + hid * L, oWd2 = obd1 + hid, obd2 = oWd2 + hid * hid, oWx = obd2 + hid,
