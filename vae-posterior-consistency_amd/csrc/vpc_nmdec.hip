@@ -276,19 +276,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     const int K = a.K, L = a.L, d = a.d;
     constexpr int YT = 2 * DT;  // head tiles: xm 0 .. DT - 1, xl DT .. 2 DT - 1
 
-    load_image<27>(lds, a.img, NdImg::total);
-    __syncthreads();
-    if (threadIdx.x < ND_LWB) lwbuf[threadIdx.x] = -INFINITY;
-    if (threadIdx.x < 128) {
-        const float wv = lds[NdImg::oWm + threadIdx.x];
-        const float e = expf(-fabsf(wv));
-        const float spv = wv > 20.f ? wv : log1pf(expf(wv));
-        SP[threadIdx.x] = spv;
-        ISP[threadIdx.x] = 1.f / spv;
-        SG[threadIdx.x] = wv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    }
-    __syncthreads();
-
     // the lane's row inside a tile: replica k of tile-local data row bl
     const int r0 = 16 * w + c;
     const int bl = r0 / K, k = r0 - bl * K;
@@ -395,6 +382,20 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         if (tid < a.nb * 8) *reinterpret_cast<f32x4*>(st + ND_HD + (tid >> 3) * 32 + ((tid >> 2) & 1) * 16 + 4 * (tid & 3)) = pfh;
     };
     if ((int)blockIdx.x < a.ntiles) request_inputs(blockIdx.x);
+    // (the first tile's inputs are on their way while the weight image is copied: one tile per workgroup at the reference's batch 128)
+    load_image<27>(lds, a.img, NdImg::total);
+    __syncthreads();
+    if (threadIdx.x < ND_LWB) lwbuf[threadIdx.x] = -INFINITY;
+    if (threadIdx.x < 128) {
+        const float wv = lds[NdImg::oWm + threadIdx.x];
+        const float e = expf(-fabsf(wv));
+        const float spv = wv > 20.f ? wv : log1pf(expf(wv));
+        SP[threadIdx.x] = spv;
+        ISP[threadIdx.x] = 1.f / spv;
+        SG[threadIdx.x] = wv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    }
+    __syncthreads();
+
     NSTP(0);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
