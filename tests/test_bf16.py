@@ -28,6 +28,13 @@ def _t(a):
     return torch.from_numpy(np.array(a)).to(DEV)
 
 
+@pytest.fixture(autouse=True)
+def _requested_engine(monkeypatch):
+    """These tests are about the bf16 engine's kernels.  FusedTrainer routes small batches of EVERY precision to the fp32 N-split
+    kernel (csrc/vpc_small.hip: more accurate and faster there); VPC_STEP_SMALL=0 keeps the engine that was asked for."""
+    monkeypatch.setenv("VPC_STEP_SMALL", "0")
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))

@@ -27,6 +27,13 @@ PRECS = ["bf16x3", "bf16"]
 LOSS_TOL, GRAD_TOL = 1e-5, 1e-3
 
 
+@pytest.fixture(autouse=True)
+def _requested_engine(monkeypatch):
+    """These tests are about the bf16 engine's kernels.  FusedTrainer routes small batches of EVERY precision to the fp32 N-split
+    kernel (csrc/vpc_small.hip: more accurate and faster there); VPC_STEP_SMALL=0 keeps the engine that was asked for."""
+    monkeypatch.setenv("VPC_STEP_SMALL", "0")
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
@@ -217,3 +224,23 @@ def test_bf16_engine_microtest(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
+def test_small_batches_run_the_f32_kernel_in_every_precision(prec, monkeypatch):
+    """Without VPC_STEP_SMALL=0 a FusedTrainer(precision=bf16 | bf16x3) step on the reference's 64-row vectors runs the fp32
+    N-split kernel: bit-equal to the fp32 trainer's step, i.e. inside the fp32 tolerances of tests/test_gpu_parity.py."""
+    monkeypatch.delenv("VPC_STEP_SMALL", raising=False)
+    g = load_golden("reg_d128.npz")
+    P = golden_params(g)
+    outs = []
+    for p_ in ("f32", prec):
+        m = _model(vpc.Reg_VAE, 128, P)
+        tr = vpc.FusedTrainer(m, precision=p_)
+        tr.step(_t(g["x"]), _t(g["mask"]), _t(g["mask_p"]), _t(g["eps_q"]), _t(g["eps_p"]), None, update=False, alpha=1.0)
+        assert tr.dominant_launch() == "step_small"
+        outs.append((tr.loss_value(), tr.grad.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    loss, _, _, _ = O.closed_form_reg_step(P, L, g["x"], g["mask"], g["mask_p"], g["eps_q"], g["eps_p"], alpha=1.0)
+    assert abs(outs[1][0] - loss) <= 2e-5 * abs(loss)

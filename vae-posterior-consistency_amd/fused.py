@@ -206,13 +206,18 @@ class FusedTrainer:
             raise ValueError(f"rows [{row_lo}, {row_lo + B}) are not inside the global batch of {Bg}")
         co = self.coefficients(epoch, alpha, beta, beta_annealing)
         two = not self.vanilla
-        use_step = bool(self.prec) and self._step_ok and ops.step_fused_applicable(B, dk, Ld, 2 if two else 1)
+        # Small batches run the fp32 N-split kernel (csrc/vpc_small.hip) in EVERY precision: `precision` bounds the rounding a step may
+        # use, and at these sizes the fp32 kernel is both the most accurate and the fastest form (B = 64: 41 us against 62 us for the
+        # bf16 engine's small-shape kernels).  VPC_STEP_SMALL=0 in the environment keeps the requested engine (tests of its kernels).
+        use_small = not lay.mask_augm and B <= ops.step_small_max_rows()  # (<= 16 x CUs rows)
+        self._used_step_small = use_small
+        use_step = (not use_small) and bool(self.prec) and self._step_ok and ops.step_fused_applicable(B, dk, Ld, 2 if two else 1)
         self._used_step_fused = use_step
         # the model's fp32 images (what the fp32 kernels read and the Adam launches re-pack); the whole-step bf16 kernel has its
         # own image and leaves these stale (invalidate_images below), so it must not ask for them every step
         img = None if use_step else m._images()
         enc_img, dec_img = (None, None) if use_step else (img[:lay.enc_img], img[lay.enc_img:])
-        if self.prec:  # bf16 images, re-packed from the flat parameters after an optimiser step (lazily, see __init__)
+        if self.prec and not use_small:  # bf16 images, re-packed from the flat parameters after an optimiser step (lazily, see __init__)
             enc_img, dec_img = self.img_bf[:self.enc_img_bf], self.img_bf[self.enc_img_bf:]
             kind = "step" if use_step else "pair"
             if self._stale[kind]:
@@ -258,10 +263,8 @@ class FusedTrainer:
         masks = [mask, mask_p] if two else [mask]
         epss = [eq, ep] if two else [eq]
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
-        use_small = (not self.prec) and not lay.mask_augm and B <= ops.step_small_max_rows()  # (<= 32 x CUs rows)
-        self._used_step_small = use_small
         if use_small:
-            # ---- fp32, small batch: the whole step in ONE launch, 16-row tiles with the feature tiles split over the waves
+            # ---- small batch (fp32 arithmetic in every precision): the whole step in ONE launch, 16-row tiles with the feature tiles split over the waves
             nbE = nbD = self._timed("step_small", ops.step_small_f32, x, enc_img, dec_img, masks, maskB, co["cA"], co["cE"], epss,
                                     eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,
                                     self.partD, self.loss_part, dk, Ld)
