@@ -163,48 +163,53 @@ __global__ void eddi_reduce_kernel(const float* __restrict__ part, int G, int n,
     dAC[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// chain rule from (dA, dC) [K][d] to the four parameter tensors: one thread per output element
-// (d*K + d + K*(2+K) + K of them), each a short dot product
+// chain rule from (dA, dC) [K][d] to the four parameter tensors.  dE / dt (d K + d outputs, K-term dot products): one thread per
+// output (workgroups [0, gA)); dW / dc (K (2 + K) + K outputs, d-term dot products): one WAVE per output, lanes over j, DPP sum -
+// as one thread per output these were 128 dependent-latency loads in a row on 13 workgroups: 36 us of a 0.3 ms step at d = 128
 __global__ __launch_bounds__(256) void eddi_param_bwd_kernel(const float* __restrict__ dAC, const float* __restrict__ E,
                                                              const float* __restrict__ tb, const float* __restrict__ Wp,
                                                              float* __restrict__ gE, float* __restrict__ gtb,
                                                              float* __restrict__ gWp, float* __restrict__ gcp, int d,
-                                                             int K, int accumulate) {
+                                                             int K, int accumulate, int gA) {
     const float* dA = dAC;
     const float* dC = dAC + (long)K * d;
     auto put = [&](float* p, float v) { *p = accumulate ? *p + v : v; };
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d * K) {  // dE[j][e] = sum_k W_E[k][e] dA[k][j]
-        const int j = i / K, e = i % K;
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + e] * dA[(long)k * d + j];
-        put(gE + i, s);
+    if ((int)blockIdx.x < gA) {
+        int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < d * K) {  // dE[j][e] = sum_k W_E[k][e] dA[k][j]
+            const int j = i / K, e = i % K;
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + e] * dA[(long)k * d + j];
+            put(gE + i, s);
+            return;
+        }
+        i -= d * K;
+        if (i < d) {  // dt[j] = sum_k w_t[k] dC[k][j]
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + K] * dC[(long)k * d + i];
+            put(gtb + i, s);
+        }
         return;
     }
-    i -= d * K;
-    if (i < d) {  // dt[j] = sum_k w_t[k] dC[k][j]
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += Wp[(long)k * (2 + K) + 1 + K] * dC[(long)k * d + i];
-        put(gtb + i, s);
-        return;
-    }
-    i -= d;
+    const int lane = threadIdx.x & 63;
+    int i = ((int)blockIdx.x - gA) * 4 + (threadIdx.x >> 6);  // one wave per output
+    float s = 0.f;
     if (i < K * (2 + K)) {  // dW[k][0] = sum_j dA; dW[k][1+e] = sum_j dA E[j][e]; dW[k][1+K] = sum_j dC t[j]
         const int k = i / (2 + K), c = i % (2 + K);
-        float s = 0.f;
-        if (c == 0) for (int j = 0; j < d; ++j) s += dA[(long)k * d + j];
-        else if (c == 1 + K) for (int j = 0; j < d; ++j) s += dC[(long)k * d + j] * tb[j];
-        else for (int j = 0; j < d; ++j) s += dA[(long)k * d + j] * E[(long)j * K + (c - 1)];
-        put(gWp + i, s);
+        for (int j = lane; j < d; j += 64)
+            s += c == 0 ? dA[(long)k * d + j] : c == 1 + K ? dC[(long)k * d + j] * tb[j] : dA[(long)k * d + j] * E[(long)j * K + (c - 1)];
+        s = wave_sum_dpp(s);
+        if (lane == 0) put(gWp + i, s);
         return;
     }
     i -= K * (2 + K);
     if (i < K) {  // dc[k] = sum_j dC[k][j]
-        float s = 0.f;
-        for (int j = 0; j < d; ++j) s += dC[(long)i * d + j];
-        put(gcp + i, s);
+        for (int j = lane; j < d; j += 64) s += dC[(long)i * d + j];
+        s = wave_sum_dpp(s);
+        if (lane == 0) put(gcp + i, s);
     }
 }
+
 
 static int eddi_blocks(long B) {
     long blocks = (B + 3) / 4;
@@ -277,9 +282,9 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
 #undef VPC_EDDI_BWD
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
     hipLaunchKernelGGL(eddi_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, G, n, dAC);
-    const int n_out = d * K + d + K * (2 + K) + K;
-    hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp,
-                       gcp, d, K, accumulate);
+    const int gA = (d * K + d + 255) / 256, gB = (K * (2 + K) + K + 3) / 4;
+    hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3(gA + gB), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp, gcp, d, K,
+                       accumulate, gA);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

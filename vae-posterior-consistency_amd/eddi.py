@@ -19,7 +19,7 @@ from . import _lib as L
 from . import ops
 from ._lib import check, lib, ptr, require_cuda, stream_ptr
 from .models import MAX_EPOCH, Reg_VAE, vanilla_VAE
-from .notmiwae import ACT_NONE, ACT_RELU, linear_dgrad, linear_fwd, linear_wgrad, nm_sample, nm_sample_bwd
+from .notmiwae import ACT_NONE, ACT_RELU, linear_dgrad, linear_fwd, linear_wgrad, nm_sample, nm_sample_bwd, wgrad_reduce
 from .ops import as_mask_u8
 
 H1, H2 = 100, 50  # VAE.py:694-698 hard-codes 100 / 50
@@ -275,6 +275,11 @@ class EDDITrainer:
         self.eps_buf = e(3, B, LP)
         self.mask_p_buf = torch.empty(B, d, dtype=torch.uint8, device=dev)
         self.front_scratch = e(int(lib().vpc_eddi_front_scratch(P * B, d, K)))
+        # per-layer partial buffers of the trunk's three weight gradients: summed by ONE launch (vpc_linear_wgrad_reduce)
+        R = P * B
+        self.wg_shapes = [(R, 2 * m.latent_dim, H2), (R, H2, H1), (R, H1, K)]
+        self.wg_scratch = [e(int(lib().vpc_linear_wgrad_scratch(*sh))) for sh in self.wg_shapes]
+        self._wg_cache = {}
         self._B = B
 
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=0.5, beta=1.0,
@@ -350,12 +355,16 @@ class EDDITrainer:
         # ---- encoder backward
         self.dheads.view(P, B, 2, Ld).copy_(self.dlat[..., :Ld].permute(0, 2, 1, 3))
         g = self.g
-        linear_wgrad(self.dheads, self.h2, g[4], g[5], R, 2 * Ld, H2)
+        # (the three weight gradients leave their GEMMs as partials and are summed by ONE launch: two launches less per step)
+        sc = self.wg_scratch
+        linear_wgrad(self.dheads, self.h2, None, None, R, 2 * Ld, H2, scratch=sc[0])
         linear_dgrad(self.dheads, W3, self.dh2, R, 2 * Ld, H2, x_out=self.h2, act_prev=ACT_RELU)
-        linear_wgrad(self.dh2, self.h1, g[2], g[3], R, H2, H1)
+        linear_wgrad(self.dh2, self.h1, None, None, R, H2, H1, scratch=sc[1])
         linear_dgrad(self.dh2, W2, self.dh1, R, H2, H1, x_out=self.h1, act_prev=ACT_RELU)
-        linear_wgrad(self.dh1, self.agg, g[0], g[1], R, H1, K)
+        linear_wgrad(self.dh1, self.agg, None, None, R, H1, K, scratch=sc[2])
         linear_dgrad(self.dh1, W1, self.dagg, R, H1, K)
+        wgrad_reduce([(sc[0], R, 2 * Ld, H2, g[4], g[5], False), (sc[1], R, H2, H1, g[2], g[3], False),
+                      (sc[2], R, H1, K, g[0], g[1], False)], self._wg_cache)
         eddi_front_bwd(x, masks[0], self.AC, self.dagg, E, tb, Wp, g[12], g[13], g[14], g[15], B, d, K,
                        mask2_u8=masks[1] if two else None, scratch=self.front_scratch)
         if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
