@@ -33,17 +33,43 @@ __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restric
                                                           float* __restrict__ W1T, int n, int d, int M, int Mp) {
     const int f = threadIdx.x;  // 0..127: hidden unit (100 = constant, 101..111 = padding), >= 112 idle
     const int pf = f < H1P ? pos1_full(f) : 0;
-    if (blockIdx.x == (unsigned)n) {  // last block: W1T[u][f] = W1[f][u]
-        for (int u = 0; u < d; ++u)
-            if (f < H1P) W1T[u * H1P + pf] = f < H1 ? W1[f * d + u] : 0.f;
+    if (blockIdx.x >= (unsigned)n) {  // trailing blocks: W1T[u][f] = W1[f][u], 8 input columns per block
+        const int u0 = 8 * ((int)blockIdx.x - n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = u0 + k;
+            if (u < d && f < H1P) W1T[u * H1P + pf] = f < H1 ? W1[f * d + u] : 0.f;
+        }
         return;
     }
     const int r = blockIdx.x, T = d - 1;
+    // base[f] = b1[f] + sum_i W1[f][i] x[r][i] mask[r][i]: each wave takes every second unit, lanes over i (the rows of W1 are read
+    // coalesced; one thread per unit walked its row with a stride of d floats: 128 dependent loads, 35 us for this launch)
+    __shared__ float base_sh[H1P];
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float xm[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = lane + 64 * k;
+            xm[k] = i < d ? x[(long)r * d + i] * (mask[(long)r * d + i] ? 1.f : 0.f) : 0.f;
+        }
+        for (int u = wv; u < H1; u += 2) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = lane + 64 * k;
+                if (i < d) sacc += W1[u * d + i] * xm[k];
+            }
+            sacc = wave_sum_dpp(sacc);
+            if (lane == 0) base_sh[u] = b1[u] + sacc;
+        }
+    }
+    __syncthreads();
     if (f >= H1P) return;
     float base = 0.f, wT = 0.f;
     if (f < H1) {
-        base = b1[f];
-        for (int i = 0; i < d; ++i) base += W1[f * d + i] * x[(long)r * d + i] * (mask[(long)r * d + i] ? 1.f : 0.f);
+        base = base_sh[f];
         wT = W1[f * d + T];
     }
     const float xT = x[(long)r * d + T], mT = mask[(long)r * d + T] ? 1.f : 0.f;
@@ -182,7 +208,7 @@ extern "C" int vpc_reward_matrix(const float* x, const uint8_t* mask, const floa
     if (!aligned16(pre) || !aligned16(stat) || !aligned16(w1t)) return VPC_ERR_ARG;
     const int Mp = (M + 15) / 16 * 16;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(reward_prep_kernel, dim3(n + 1), dim3(128), 0, s, x, mask, im, W1, b1, pre, w1t, n, d, M, Mp);
+    hipLaunchKernelGGL(reward_prep_kernel, dim3(n + (d + 7) / 8), dim3(128), 0, s, x, mask, im, W1, b1, pre, w1t, n, d, M, Mp);
     RewardArgs a{enc_img, pre, w1t, im, mask, stat, R, n, d, L, M, Mp};
     const EncImg imd(dt_for(d));
     const size_t lds = sizeof(float) * (imd.total - imd.oW2);
