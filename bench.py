@@ -50,7 +50,8 @@ def flops_per_sample(d, L, passes=2):
     enc = enc_f + (2 * enc_f - d * 100)
     dec = 3 * dec_f
     return dict(total=2 * passes * (enc + dec), decoder_fused=2 * passes * dec, encoder_fwd=2 * passes * enc_f,
-                encoder_bwd=2 * passes * (2 * enc_f - d * 100), step_fused=2 * passes * (enc + dec))
+                encoder_bwd=2 * passes * (2 * enc_f - d * 100), step_fused=2 * passes * (enc + dec),
+                step_small=2 * passes * (enc + dec))
 
 
 def _traffic_table():
@@ -481,7 +482,8 @@ def main():
     rows = f"B={B} per GPU" if args.scaling == "weak" else f"global B={Bg} sharded {B} rows per GPU"
     kname = {"decoder_fused": ("vpc::dec_kernel<8,true,FUSED,1> (small-batch shape)" if r["small"] else "vpc::dec8_kernel<8,true>")
                               + " (vpc_decoder_fused)",
-             "step_fused": "vpc::step_bf16_kernel<8> (vpc_step_fused_bf16: encoder fwd + decoder + loss + all backward)"}[dom]
+             "step_fused": "vpc::step_bf16_kernel<8> (vpc_step_fused_bf16: encoder fwd + decoder + loss + all backward)",
+             "step_small": "vpc::step_small_kernel<8> (vpc_step_small_f32: the whole step, 16-row tiles split over the waves)"}[dom]
     out = {
         "metric": "training samples/sec (ELBO+consistency step), B=65536 d=128",
         "value": value, "unit": "samples/s", "n_gpus": r["seen"], "steps": args.steps, "warmup": args.warmup,
