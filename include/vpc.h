@@ -241,7 +241,7 @@ int vpc_rccl_comm_destroy(void* comm);
  * the imputed target between MC samples (evaluate.py:531-536).  x [n][d], mask [n][d] bytes, im [M][n][d]
  * (MC imputations, evaluate.py:396-414), W1 [100][d] / b1 [100] = seq_encoder.0 (flat parameter views),
  * enc_img = packed encoder image; pre / stat / w1t are scratch buffers of the sizes vpc_reward_scratch returns
- * (16-byte aligned).  The target is the last column, as in the reference. */
+ * (16-byte aligned; w1t also holds the rows' candidate lists).  The target is the last column, as in the reference. */
 int vpc_reward_scratch(int n, int d, int M, long* pre_floats, long* stat_floats, long* w1t_floats);
 int vpc_reward_matrix(const float* x, const uint8_t* mask, const float* im, const float* W1, const float* b1,
                       const float* enc_img, float* pre, float* stat, float* w1t, float* R, int n, int d, int L, int M,

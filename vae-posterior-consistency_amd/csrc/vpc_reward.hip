@@ -30,7 +30,8 @@ constexpr int STAT = 64;  // floats per (n, m): [chain I | chain II] x [mean til
 __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ im, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, float* __restrict__ pre,
-                                                          float* __restrict__ W1T, int n, int d, int M, int Mp) {
+                                                          float* __restrict__ W1T, int* __restrict__ cand,
+                                                          float* __restrict__ R, int n, int d, int M, int Mp) {
     const int f = threadIdx.x;  // 0..127: hidden unit (100 = constant, 101..111 = padding), >= 112 idle
     const int pf = f < H1P ? pos1_full(f) : 0;
     if (blockIdx.x >= (unsigned)n) {  // trailing blocks: W1T[u][f] = W1[f][u], 8 input columns per block
@@ -43,6 +44,22 @@ __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restric
         return;
     }
     const int r = blockIdx.x, T = d - 1;
+    // the row's candidates: cand[r][0] = their number, cand[r][1 + k] = the k-th feature u < d - 1 that is not observed yet, in
+    // ascending order; observed features get the reference's R = -1e4 here (evaluate.py:424-433)
+    {
+        __shared__ int cnt0;
+        const int u = threadIdx.x;
+        const bool isc = u < T && !mask[(long)r * d + u];
+        const unsigned long long bal = __ballot(isc);
+        if (threadIdx.x == 0) cnt0 = __popcll(bal);
+        __syncthreads();
+        const int before = __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull)) + (threadIdx.x >= 64 ? cnt0 : 0);
+        int* cr = cand + (long)r * d;
+        if (isc) cr[1 + before] = u;
+        if (u < T && !isc) R[(long)r * T + u] = -1e4f;
+        if (threadIdx.x == 127) cr[0] = before + (isc ? 1 : 0);
+        __syncthreads();
+    }
     // base[f] = b1[f] + sum_i W1[f][i] x[r][i] mask[r][i]: each wave takes every second unit, lanes over i (the rows of W1 are read
     // coalesced; one thread per unit walked its row with a stride of d floats: 128 dependent loads, 35 us for this launch)
     __shared__ float base_sh[H1P];
@@ -94,13 +111,18 @@ struct RewardArgs {
     const float* W1T;     // [d][112]
     const float* im;      // [M][n][d]
     const uint8_t* mask;  // [n][d]
+    const int* cand;      // [n][d]: count, then the row's candidate features (reward_prep_kernel)
     float* stat;          // [n][Mp][64]
     float* R;             // [n][d-1]
     int n, d, L, M, Mp;
 };
 
 // MODE 0 (A): items = rows; writes stat[n][m] = {mean_I, logvar_I, mean_II, logvar_II} (16-float tiles)
-// MODE 1 (B): items = (row, candidate); reads stat, writes R
+// MODE 1 (B): items = (row, chunk of RW_CH candidates); reads stat, writes R.  A chunk's (candidate, sample) pairs are FLATTENED
+// into 16-column MFMA tiles: column c of tile t is pair f = 16 t + c -> candidate f / M, sample f % M.  (Per candidate the M
+// samples padded to a multiple of 16 issued 64 columns for M = 50 - 22 % of the matrix work on padding, 50 % at M = 8; a full
+// chunk of 8 candidates x 50 samples is exactly 25 tiles.)
+constexpr int RW_CH = 8;
 template <int MODE>
 __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -111,38 +133,46 @@ __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) 
     const float* W3 = lds + (imd.oW3 - imd.oW2);
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
-    const long nitems = MODE == 0 ? a.n : (long)a.n * (a.d - 1);
+    const int nch = (a.d - 1 + RW_CH - 1) / RW_CH;  // chunks per row (upper bound)
+    const long nitems = MODE == 0 ? a.n : (long)a.n * nch;
     const float invM = 1.f / (float)a.M;
 
     for (long item = (long)blockIdx.x * RW_WAVES + w; item < nitems; item += (long)gridDim.x * RW_WAVES) {
-        const int r = MODE == 0 ? (int)item : (int)(item / (a.d - 1));
-        const int u = MODE == 0 ? 0 : (int)(item % (a.d - 1));
-        if (MODE == 1 && a.mask[(long)r * a.d + u]) {  // already observed: the reference leaves R at -1e4
-            if (lane == 0) a.R[(long)r * (a.d - 1) + u] = -1e4f;
-            continue;
-        }
-        f32x4 w1u[H1T];
+        const int r = MODE == 0 ? (int)item : (int)(item / nch);
+        const int ch = MODE == 0 ? 0 : (int)(item % nch);
+        int ncand = 0;
+        const int* cl = a.cand + (long)r * a.d + 1 + RW_CH * ch;
         if (MODE == 1) {
-#pragma unroll
-            for (int t = 0; t < H1T; ++t) w1u[t] = *reinterpret_cast<const f32x4*>(a.W1T + (long)u * H1P + 16 * t + 4 * q);
+            ncand = a.cand[(long)r * a.d] - RW_CH * ch;
+            if (ncand <= 0) continue;
+            if (ncand > RW_CH) ncand = RW_CH;
         }
-        float acc = 0.f;
-        for (int mt = 0; mt < a.Mp / 16; ++mt) {
+        const int total = MODE == 0 ? a.Mp : ncand * a.M;  // columns of this item
+        float acc[RW_CH];
+#pragma unroll
+        for (int k = 0; k < RW_CH; ++k) acc[k] = 0.f;
+        for (int t0 = 0; t0 < total; t0 += 16) {
             asm volatile("" ::: "memory");
             int cc = c, qq = q;
             launder(cc, qq);
-            const int m = 16 * mt + c;
-            const bool live = m < a.M;
+            const int f = t0 + c;
+            const bool live = MODE == 0 ? f < a.M : f < total;
+            int kk = 0, m = f;
+            if (MODE == 1) {
+                kk = live ? f / a.M : 0;
+                m = live ? f - kk * a.M : 0;
+            }
+            const int u = MODE == 1 ? cl[kk] : 0;
             const float imu = (MODE == 1 && live) ? a.im[((long)m * a.n + r) * a.d + u] : 0.f;
             const float* pp = a.pre + (((long)r * a.Mp + m) * 2) * H1P + 4 * q;
             f32x4 h1[2][H1T];
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int chn = 0; chn < 2; ++chn)
 #pragma unroll
                 for (int t = 0; t < H1T; ++t) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(pp + ch * H1P + 16 * t);
-                    if (MODE == 1) v += w1u[t] * imu;
-                    h1[ch][t] = relu4(v);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(pp + chn * H1P + 16 * t);
+                    if (MODE == 1) v += *reinterpret_cast<const f32x4*>(a.W1T + (long)u * H1P + 16 * t + 4 * q) * imu;
+                    h1[chn][t] = relu4(v);
                 }
             f32x4 h2[2][H2T];
 #pragma unroll
@@ -162,25 +192,31 @@ __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) 
                 *reinterpret_cast<f32x4*>(st + 32) = mu[1];
                 *reinterpret_cast<f32x4*>(st + 48) = lv[1];
             } else {
+                float val = 0.f;
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const f32x4 ma = *reinterpret_cast<const f32x4*>(st + 32 * ch);
-                    const f32x4 la = *reinterpret_cast<const f32x4*>(st + 32 * ch + 16);
+                for (int chn = 0; chn < 2; ++chn) {
+                    const f32x4 ma = *reinterpret_cast<const f32x4*>(st + 32 * chn);
+                    const f32x4 la = *reinterpret_cast<const f32x4*>(st + 32 * chn + 16);
                     float kl = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float dm = mu[ch][j] - ma[j];
-                        const float t = dm * dm * expf(-0.5f * la[j]) + expf(lv[ch][j] - la[j]) - 1.f - lv[ch][j] + la[j];
+                        const float dm = mu[chn][j] - ma[j];
+                        const float t = dm * dm * expf(-0.5f * la[j]) + expf(lv[chn][j] - la[j]) - 1.f - lv[chn][j] + la[j];
                         kl += (4 * q + j < a.L) ? t : 0.f;
                     }
                     kl = live ? 0.5f * kl : 0.f;
-                    acc += ch == 0 ? kl : -kl;
+                    val += chn == 0 ? kl : -kl;
                 }
+#pragma unroll
+                for (int k = 0; k < RW_CH; ++k) acc[k] += kk == k ? val : 0.f;
             }
         }
         if (MODE == 1) {
-            acc = wave_sum(acc);
-            if (lane == 0) a.R[(long)r * (a.d - 1) + u] = acc * invM;
+#pragma unroll
+            for (int k = 0; k < RW_CH; ++k) {
+                const float sacc = wave_sum(acc[k]);
+                if (lane == 0 && k < ncand) a.R[(long)r * (a.d - 1) + cl[k]] = sacc * invM;
+            }
         }
     }
 }
@@ -195,7 +231,7 @@ extern "C" int vpc_reward_scratch(int n, int d, int M, long* pre_floats, long* s
     const long Mp = (M + 15) / 16 * 16;
     if (pre_floats) *pre_floats = (long)n * Mp * 2 * H1P;
     if (stat_floats) *stat_floats = (long)n * Mp * STAT;
-    if (w1t_floats) *w1t_floats = (long)d * H1P;
+    if (w1t_floats) *w1t_floats = (long)d * H1P + (long)n * d;  // W1^T, then the rows' candidate lists (ints)
     return VPC_OK;
 }
 
@@ -208,14 +244,15 @@ extern "C" int vpc_reward_matrix(const float* x, const uint8_t* mask, const floa
     if (!aligned16(pre) || !aligned16(stat) || !aligned16(w1t)) return VPC_ERR_ARG;
     const int Mp = (M + 15) / 16 * 16;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(reward_prep_kernel, dim3(n + (d + 7) / 8), dim3(128), 0, s, x, mask, im, W1, b1, pre, w1t, n, d, M, Mp);
-    RewardArgs a{enc_img, pre, w1t, im, mask, stat, R, n, d, L, M, Mp};
+    int* cand = reinterpret_cast<int*>(w1t + (long)d * H1P);
+    hipLaunchKernelGGL(reward_prep_kernel, dim3(n + (d + 7) / 8), dim3(128), 0, s, x, mask, im, W1, b1, pre, w1t, cand, R, n, d, M, Mp);
+    RewardArgs a{enc_img, pre, w1t, im, mask, cand, stat, R, n, d, L, M, Mp};
     const EncImg imd(dt_for(d));
     const size_t lds = sizeof(float) * (imd.total - imd.oW2);
     const int cap = num_cus() * 3;
     int gA = (n + RW_WAVES - 1) / RW_WAVES;
     if (gA > cap) gA = cap;
-    long itemsB = (long)n * (d - 1);
+    long itemsB = (long)n * ((d - 1 + RW_CH - 1) / RW_CH);
     int gB = (int)((itemsB + RW_WAVES - 1) / RW_WAVES < cap ? (itemsB + RW_WAVES - 1) / RW_WAVES : cap);
     if (!lds_attr_done(reinterpret_cast<const void*>(reward_chain_kernel<0>), lds)) return VPC_ERR_HIP;
     if (!lds_attr_done(reinterpret_cast<const void*>(reward_chain_kernel<1>), lds)) return VPC_ERR_HIP;
