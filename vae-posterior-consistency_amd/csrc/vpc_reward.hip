@@ -32,6 +32,7 @@ __global__ __launch_bounds__(128) void reward_prep_kernel(const float* __restric
                                                           const float* __restrict__ b1, float* __restrict__ pre,
                                                           float* __restrict__ W1T, int* __restrict__ cand,
                                                           float* __restrict__ R, int n, int d, int M, int Mp) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cand[(long)n * d] = 0;  // work counter of reward_chain_kernel<1>
     const int f = threadIdx.x;  // 0..127: hidden unit (100 = constant, 101..111 = padding), >= 112 idle
     const int pf = f < H1P ? pos1_full(f) : 0;
     if (blockIdx.x >= (unsigned)n) {  // trailing blocks: W1T[u][f] = W1[f][u], 8 input columns per block
@@ -112,6 +113,7 @@ struct RewardArgs {
     const float* im;      // [M][n][d]
     const uint8_t* mask;  // [n][d]
     const int* cand;      // [n][d]: count, then the row's candidate features (reward_prep_kernel)
+    int* next_item;       // MODE 1 work counter (zeroed by reward_prep_kernel)
     float* stat;          // [n][Mp][64]
     float* R;             // [n][d-1]
     int n, d, L, M, Mp;
@@ -122,7 +124,7 @@ struct RewardArgs {
 // into 16-column MFMA tiles: column c of tile t is pair f = 16 t + c -> candidate f / M, sample f % M.  (Per candidate the M
 // samples padded to a multiple of 16 issued 64 columns for M = 50 - 22 % of the matrix work on padding, 50 % at M = 8; a full
 // chunk of 8 candidates x 50 samples is exactly 25 tiles.)
-constexpr int RW_CH = 8;
+constexpr int RW_CH = 4;
 template <int MODE>
 __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -137,7 +139,14 @@ __global__ __launch_bounds__(RW_THREADS) void reward_chain_kernel(RewardArgs a) 
     const long nitems = MODE == 0 ? a.n : (long)a.n * nch;
     const float invM = 1.f / (float)a.M;
 
-    for (long item = (long)blockIdx.x * RW_WAVES + w; item < nitems; item += (long)gridDim.x * RW_WAVES) {
+    long item = (long)blockIdx.x * RW_WAVES + w;
+    auto next = [&]() {
+        if (MODE == 0) { item += (long)gridDim.x * RW_WAVES; return; }
+        int v = 0;
+        if (lane == 0) v = atomicAdd(a.next_item, 1);
+        item = (long)gridDim.x * RW_WAVES + __builtin_amdgcn_readfirstlane(v);  // (the first round is the launch's own grid)
+    };
+    for (; item < nitems; next()) {
         const int r = MODE == 0 ? (int)item : (int)(item / nch);
         const int ch = MODE == 0 ? 0 : (int)(item % nch);
         int ncand = 0;
@@ -231,7 +240,7 @@ extern "C" int vpc_reward_scratch(int n, int d, int M, long* pre_floats, long* s
     const long Mp = (M + 15) / 16 * 16;
     if (pre_floats) *pre_floats = (long)n * Mp * 2 * H1P;
     if (stat_floats) *stat_floats = (long)n * Mp * STAT;
-    if (w1t_floats) *w1t_floats = (long)d * H1P + (long)n * d;  // W1^T, then the rows' candidate lists (ints)
+    if (w1t_floats) *w1t_floats = (long)d * H1P + (long)n * d + 4;  // W1^T, the rows' candidate lists (ints), a work counter
     return VPC_OK;
 }
 
@@ -246,10 +255,10 @@ extern "C" int vpc_reward_matrix(const float* x, const uint8_t* mask, const floa
     hipStream_t s = (hipStream_t)stream;
     int* cand = reinterpret_cast<int*>(w1t + (long)d * H1P);
     hipLaunchKernelGGL(reward_prep_kernel, dim3(n + (d + 7) / 8), dim3(128), 0, s, x, mask, im, W1, b1, pre, w1t, cand, R, n, d, M, Mp);
-    RewardArgs a{enc_img, pre, w1t, im, mask, cand, stat, R, n, d, L, M, Mp};
+    RewardArgs a{enc_img, pre, w1t, im, mask, cand, cand + (long)n * d, stat, R, n, d, L, M, Mp};
     const EncImg imd(dt_for(d));
     const size_t lds = sizeof(float) * (imd.total - imd.oW2);
-    const int cap = num_cus() * 3;
+    const int cap = num_cus() * 3;  // (2 and 4 - 6 resident workgroups per CU measured slower)
     int gA = (n + RW_WAVES - 1) / RW_WAVES;
     if (gA > cap) gA = cap;
     long itemsB = (long)n * ((d - 1 + RW_CH - 1) / RW_CH);
