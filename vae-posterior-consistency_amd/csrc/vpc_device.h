@@ -359,6 +359,32 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
            (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
 }
 
+// Sum of S partial blocks for 16 consecutive outputs per 256-thread workgroup: thread (o = tid & 15, g = tid >> 4) adds the blocks
+// g, g + 16, ... of its output (four interleaved chains), the 16 group sums are combined in group order - a fixed association
+// (reproducible).  One thread per output walking ALL the blocks made the reductions of small layers behind a large batch
+// (hundreds of blocks, a few thousand outputs) 60 us launches of 20-30 workgroups.  The total comes back in the threads g == 0.
+__device__ __forceinline__ float sum_partials_16x16(const float* p, long stride, int S, bool valid, float (*sh)[16]) {
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        int sp = g;
+        for (; sp + 48 < S; sp += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += p[(long)(sp + 16 * u) * stride];
+        }
+        for (; sp < S; sp += 16) acc[0] += p[(long)sp * stride];
+    }
+    sh[g][o] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    float t = 0.f;
+    if (g == 0) {
+        t = sh[0][o];
+#pragma unroll
+        for (int gg = 1; gg < 16; ++gg) t += sh[gg][o];
+    }
+    return t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

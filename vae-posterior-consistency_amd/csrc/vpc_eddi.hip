@@ -149,18 +149,13 @@ __global__ __launch_bounds__(256) void eddi_front_bwd_kernel(const float* __rest
     for (int i = threadIdx.x; i < n; i += blockDim.x) part[(long)blockIdx.x * n + i] = st[i];
 }
 
-// dAC[i] = sum over the workgroup partials (fixed order)
-__global__ void eddi_reduce_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ dAC) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += part[(long)(g + u) * n + i];
-    }
-    for (; g < G; ++g) acc[0] += part[(long)g * n + i];
-    dAC[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+// dAC[i] = sum over the workgroup partials (sum_partials_16x16: fixed order)
+__global__ __launch_bounds__(256) void eddi_reduce_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ dAC) {
+    __shared__ float sh[16][16];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = i < n;
+    const float s = sum_partials_16x16(part + (valid ? i : 0), n, G, valid, sh);
+    if (threadIdx.x < 16 && valid) dAC[i] = s;
 }
 
 // chain rule from (dA, dC) [K][d] to the four parameter tensors.  dE / dt (d K + d outputs, K-term dot products): one thread per
@@ -281,7 +276,7 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
     }
 #undef VPC_EDDI_BWD
     if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
-    hipLaunchKernelGGL(eddi_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, G, n, dAC);
+    hipLaunchKernelGGL(eddi_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, G, n, dAC);
     const int gA = (d * K + d + 255) / 256, gB = (K * (2 + K) + K + 3) / 4;
     hipLaunchKernelGGL(eddi_param_bwd_kernel, dim3(gA + gB), dim3(256), 0, st, dAC, E, tb, Wp, gE, gtb, gWp, gcp, d, K,
                        accumulate, gA);

@@ -344,23 +344,17 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linear_kernel(LinArgs a) {
     });
 }
 
-// sum the per-split partial blocks in split order (deterministic); accumulate != 0 adds to dW / db
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias_part, int S, int N,
-                                    int K, float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+// sum the per-split partial blocks (sum_partials_16x16: fixed association, deterministic); accumulate != 0 adds to dW / db
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias_part, int S,
+                                                           int N, int K, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accumulate) {
+    __shared__ float sh[16][16];
     const long n_w = (long)N * K;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_w + N) return;
-    const bool is_w = i < n_w;
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = i < n_w + N, is_w = i < n_w;
     const float* src = is_w ? part + i : bias_part + (i - n_w);
-    const long stride = is_w ? n_w : N;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // 4 interleaved chains (fixed association => deterministic)
-    int sp = 0;
-    for (; sp + 3 < S; sp += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += src[(long)(sp + u) * stride];
-    }
-    for (; sp < S; ++sp) acc[0] += src[(long)sp * stride];
-    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    const float s = sum_partials_16x16(valid ? src : part, is_w ? n_w : N, S, valid, sh);
+    if (threadIdx.x >= 16 || !valid) return;
     float* dst = is_w ? dW + i : (db ? db + (i - n_w) : nullptr);
     if (dst) *dst = accumulate ? *dst + s : s;
 }
@@ -373,26 +367,19 @@ struct WgradMany {
     int S[WGRAD_MANY], N[WGRAD_MANY], K[WGRAD_MANY], accumulate[WGRAD_MANY], first_block[WGRAD_MANY + 1];
     int n;
 };
-__global__ void wgrad_reduce_many_kernel(WgradMany a) {
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(WgradMany a) {
+    __shared__ float sh[16][16];
     int l = 0;
 #pragma unroll
     for (int i = 1; i < WGRAD_MANY; ++i)
         if (i < a.n && (int)blockIdx.x >= a.first_block[i]) l = i;
     const long n_w = (long)a.N[l] * a.K[l];
-    const long i = (long)(blockIdx.x - a.first_block[l]) * blockDim.x + threadIdx.x;
-    if (i >= n_w + a.N[l]) return;
-    const bool is_w = i < n_w;
+    const long i = (long)(blockIdx.x - a.first_block[l]) * 16 + (threadIdx.x & 15);
+    const bool valid = i < n_w + a.N[l], is_w = i < n_w;
     const float* src = is_w ? a.part[l] + i : a.part[l] + (long)a.S[l] * n_w + (i - n_w);
-    const long stride = is_w ? n_w : a.N[l];
-    const int S = a.S[l];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // the association of wgrad_reduce_kernel: bit-identical results
-    int sp = 0;
-    for (; sp + 3 < S; sp += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += src[(long)(sp + u) * stride];
-    }
-    for (; sp < S; ++sp) acc[0] += src[(long)sp * stride];
-    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // (the association of wgrad_reduce_kernel: bit-identical results)
+    const float s = sum_partials_16x16(valid ? src : a.part[l], is_w ? n_w : a.N[l], a.S[l], valid, sh);
+    if (threadIdx.x >= 16 || !valid) return;
     float* dst = is_w ? a.dW[l] + i : (a.db[l] ? a.db[l] + (i - n_w) : nullptr);
     if (dst) *dst = a.accumulate[l] ? *dst + s : s;
 }
@@ -493,7 +480,7 @@ int vpc_linear_wgrad(const float* dy, long lddy, const float* y_gate, long ldyg,
     int rc = ragged ? launch_one<LIN_WGRAD, true, 4>(a, grid, precision, st) : launch_one<LIN_WGRAD, false, 4>(a, grid, precision, st);
     if (rc != VPC_OK || !dw) return rc;  // dw == NULL: partials only, summed later by vpc_linear_wgrad_reduce
     const long n = (long)N * K + N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, scratch,
                        a.bias_part, (int)S, N, K, dw, db, accumulate);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
@@ -511,7 +498,7 @@ int vpc_linear_wgrad_reduce(int n_layers, const float* const* scratch, const lon
         a.S[l] = (int)(vpc_linear_wgrad_scratch(M[l], N[l], K[l]) / per);  // the split count vpc_linear_wgrad used
         a.N[l] = N[l]; a.K[l] = K[l]; a.accumulate[l] = accumulate[l];
         a.first_block[l] = blocks;
-        blocks += (int)((per + 255) / 256);
+        blocks += (int)((per + 15) / 16);
     }
     a.first_block[n_layers] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
