@@ -59,7 +59,11 @@ struct Lse {  // online log-sum-exp
 
 // PF: fetch sample k+1 while sample k is reduced (small batches: one row per wave, nothing else hides the latency;
 // at large batches the extra registers cost occupancy and the other waves hide it anyway)
-template <int T, bool REG, bool PF>
+// KS = 4 (small batches): the four waves of a workgroup share ONE data row, wave s takes the replicas k = s, s + 4, ...; the row's
+// l_w values meet in LDS for the log-sum-exp.  (One wave per row walks its K replicas twice, one dependent HBM round trip each: 38.8 us
+// at batch 128, K = 20 - the longest kernel of the fp32 MNAR step there.)
+constexpr int NM_KMAX = 64;  // most replicas the KS = 4 form handles
+template <int T, bool REG, bool PF, int KS = 1>
 __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
     extern __shared__ __align__(8) float lds[];
     double* stat_sh = reinterpret_cast<double*>(lds);   // [4 waves][NM_STATS]
@@ -67,14 +71,19 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
     float* sgW = spW + a.d;                              // sigmoid(W) = d softplus
     float* bb = sgW + a.d;
     float* gsh = bb + a.d;                               // [4 waves][2 d] dW | db
+    float* lw_sh = gsh + 4 * 2 * a.d;                    // KS > 1: [2][NM_KMAX] l_w of the q / p pass
+    float* dml_sh = lw_sh + 2 * NM_KMAX;                 // KS > 1, un-regularised: [4 waves][2][64] d mean | d logvar
     for (int j = threadIdx.x; j < a.d; j += blockDim.x) {
         const float w = a.W[j];
         spW[j] = softplus_f(w); sgW[j] = sigmoid_f(w); bb[j] = a.b[j];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wv = threadIdx.x >> 6;
+    const int gwave = KS == 1 ? (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
+    const int nwaves = KS == 1 ? (int)((gridDim.x * blockDim.x) >> 6) : (int)gridDim.x;
+    const int ks = KS == 1 ? 0 : wv;              // this wave's replicas: k = ks, ks + KS, ...
+    const bool lead = KS == 1 || wv == 0;         // the wave that writes what a data row has once
     const int d = a.d, K = a.K, L = a.L;
     const bool grad = a.g_xm_q != nullptr;
     float gW[T], gB[T], sp[T], sg[T], bj[T];
@@ -88,6 +97,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
     double st[NM_STATS] = {0.0, 0.0, 0.0, 0.0, 0.0};
 
     for (int b = gwave; b < a.B; b += nwaves) {
+        if (KS > 1) __syncthreads();  // the previous row's exchange buffers are read
         float x[T], m[T], mp[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
             KLq = wave_sum_dpp(lok ? 0.5f * (eq + mu_q * mu_q - 1.f - lv_q) : 0.f);
             KLp = wave_sum_dpp(lok ? 0.5f * (ep + mu_p * mu_p - 1.f - lv_p) : 0.f);
             klel = wave_sum_dpp(lok ? 0.5f * (ratio + dm * dm * ivp - 1.f - (lv_q - lv_p)) : 0.f);
-            if (grad && lok) {
+            if (grad && lok && lead) {
                 float* gq = a.g_hq + (long)b * a.ldgh;
                 float* gp = a.g_hp + (long)b * a.ldgh;
                 gq[lane] = a.kq * mu_q + a.cr * dm * ivp;
@@ -189,27 +199,42 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
         float sum_ree = 0.f, sum_req = 0.f;
         float riv[T], dn[T], rivp[T];
         Fetch cur, nxt;
-        if (PF) fetch(0, cur);
-        for (int k = 0; k < K; ++k) {
-            if (PF) { if (k + 1 < K) fetch(k + 1, nxt); } else fetch(k, cur);
+        if (PF && ks < K) fetch(ks, cur);
+        for (int k = ks; k < K; k += KS) {
+            if (PF) { if (k + KS < K) fetch(k + KS, nxt); } else fetch(k, cur);
             float lwq, lwp = 0.f, req, ree = 0.f, z, e;
             terms(cur, lwq, lwp, req, ree, riv, dn, rivp, z, e);
             if (PF) cur = nxt;
-            lq.add(lwq); ln.add(-lwq);
-            if (REG) { lp.add(lwp); sum_ree += ree; }
+            if (KS == 1) {
+                lq.add(lwq); ln.add(-lwq);
+                if (REG) lp.add(lwp);
+            } else if (lane == 0) {
+                lw_sh[k] = lwq;
+                lw_sh[NM_KMAX + k] = lwp;
+            }
+            if (REG) sum_ree += ree;
             sum_req += req;
         }
+        if (KS > 1) {  // every wave: the log-sum-exp over all K replicas, in replica order
+            __syncthreads();
+            for (int k = 0; k < K; ++k) {
+                const float lwq = lw_sh[k];
+                lq.add(lwq); ln.add(-lwq);
+                if (REG) lp.add(lw_sh[NM_KMAX + k]);
+            }
+        }
         const float lse_q = lq.value(), lse_p = REG ? lp.value() : 0.f, lse_n = ln.value();
-        st[0] += lse_q; st[1] += lse_p; st[2] += sum_ree; st[3] += klel; st[4] += sum_req;
+        if (lead) { st[0] += lse_q; st[1] += lse_p; st[3] += klel; }
+        st[2] += sum_ree; st[4] += sum_req;
         if (!grad && !a.xm_imp) continue;
 
         // ---- pass 2: softmax weights x element derivatives
         float imp[T], dmu = 0.f, dlv = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) imp[t] = 0.f;
-        if (PF) fetch(0, cur);
-        for (int k = 0; k < K; ++k) {
-            if (PF) { if (k + 1 < K) fetch(k + 1, nxt); } else fetch(k, cur);
+        if (PF && ks < K) fetch(ks, cur);
+        for (int k = ks; k < K; k += KS) {
+            if (PF) { if (k + KS < K) fetch(k + KS, nxt); } else fetch(k, cur);
             float lwq, lwp = 0.f, req, ree = 0.f, z = 0.f, e = 0.f;
             terms(cur, lwq, lwp, req, ree, riv, dn, rivp, z, e);
             const long row = (long)b * K + k;
@@ -260,13 +285,28 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 if (j < d) a.xm_imp[(long)b * d + j] = imp[t];
             }
         }
-        if (grad && !REG && lok) {
-            a.g_hq[(long)b * a.ldgh + lane] = dmu;
-            a.g_hq[(long)b * a.ldgh + L + lane] = dlv;
+        if (grad && !REG) {
+            if (KS == 1) {
+                if (lok) {
+                    a.g_hq[(long)b * a.ldgh + lane] = dmu;
+                    a.g_hq[(long)b * a.ldgh + L + lane] = dlv;
+                }
+            } else {  // the waves' shares of the sum over the replicas, added in wave order
+                dml_sh[(wv * 2 + 0) * 64 + lane] = dmu;
+                dml_sh[(wv * 2 + 1) * 64 + lane] = dlv;
+                __syncthreads();
+                if (wv == 0 && lok) {
+                    float sm = dml_sh[lane], sl = dml_sh[64 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < 4; ++ww) { sm += dml_sh[(ww * 2) * 64 + lane]; sl += dml_sh[(ww * 2 + 1) * 64 + lane]; }
+                    a.g_hq[(long)b * a.ldgh + lane] = sm;
+                    a.g_hq[(long)b * a.ldgh + L + lane] = sl;
+                }
+            }
         }
     }
     // ---- workgroup partials, combined in wave order (fixed => deterministic)
-    const int wave = threadIdx.x >> 6;
+    const int wave = wv;
     if (lane == 0)
         for (int i = 0; i < NM_STATS; ++i) stat_sh[wave * NM_STATS + i] = st[i];
     if (grad) {
@@ -386,7 +426,7 @@ __global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restri
 // The rows are walked by a grid-stride loop, so the grid is sized to ONE resident round of the variant actually
 // launched (its register count decides 2 - 6 workgroups per CU): a grid of 4 workgroups per CU on a kernel that fits
 // 3 runs two rounds and doubles the time at mid-size batches.
-template <int T, bool REG, bool PF>
+template <int T, bool REG, bool PF, int KS = 1>
 static int launch_variant(const NMLossArgs& a, int* n_blocks, size_t lds, hipStream_t st) {
     // occupancy of this variant, per (device, dynamic-LDS size): obs_dim decides the LDS footprint
     static std::mutex mu;
@@ -395,25 +435,31 @@ static int launch_variant(const NMLossArgs& a, int* n_blocks, size_t lds, hipStr
     (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> g(mu);
-        auto it = cache.find({dev, lds});
+        auto it = cache.find({dev, lds * 8 + KS});
         if (it != cache.end()) occ = it->second;
     }
     if (occ == 0) {
         int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, nm_loss_kernel<T, REG, PF>, 256, lds) != hipSuccess || o < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, nm_loss_kernel<T, REG, PF, KS>, 256, lds) != hipSuccess || o < 1)
             o = 1;
         occ = o;
         std::lock_guard<std::mutex> g(mu);
-        cache[{dev, lds}] = o;
+        cache[{dev, lds * 8 + KS}] = o;
     }
     const long cap = (long)occ * num_cus();
     if (*n_blocks > cap) *n_blocks = (int)cap;
-    hipLaunchKernelGGL((nm_loss_kernel<T, REG, PF>), dim3(*n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nm_loss_kernel<T, REG, PF, KS>), dim3(*n_blocks), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
+constexpr long NM_KS_ROWS = 1024;  // batches up to this many rows: four waves per data row (nm_loss_kernel, KS = 4)
 template <int T>
 static int launch_loss(const NMLossArgs& a, int reg, int* n_blocks, hipStream_t st) {
-    const size_t lds = (2 * 4 * NM_STATS + 3 * (size_t)a.d + 4 * 2 * (size_t)a.d) * sizeof(float);
+    const size_t lds = (2 * 4 * NM_STATS + 3 * (size_t)a.d + 4 * 2 * (size_t)a.d + 2 * NM_KMAX + 4 * 2 * 64) * sizeof(float);
+    if ((long)a.B <= NM_KS_ROWS && a.K <= NM_KMAX && !a.xm_imp) {  // one workgroup per data row
+        *n_blocks = a.B;
+        return reg ? launch_variant<T, true, true, 4>(a, n_blocks, lds, st) : launch_variant<T, false, true, 4>(a, n_blocks, lds, st);
+    }
+    if (*n_blocks > (a.B + 3) / 4) *n_blocks = (a.B + 3) / 4;  // one row per wave
     const bool pf = (long)a.B < 16L * num_cus();  // fewer rows than resident waves
     if (reg && pf) return launch_variant<T, true, true>(a, n_blocks, lds, st);
     if (reg) return launch_variant<T, true, false>(a, n_blocks, lds, st);
@@ -428,7 +474,7 @@ using namespace vpc;
 extern "C" {
 
 int vpc_nm_loss_blocks(long B) {
-    long blocks = (B + 3) / 4;
+    long blocks = B <= NM_KS_ROWS ? B : (B + 3) / 4;  // (small batches: one workgroup per data row)
     const long cap = 8L * num_cus();  // upper bound of one resident round (the launch trims it to the variant's occupancy)
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
