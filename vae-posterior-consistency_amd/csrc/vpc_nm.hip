@@ -408,14 +408,27 @@ __global__ void nm_sample_bwd_kernel(const float* __restrict__ dz, long lddz, co
     const int l = (int)(i % L);
     const long b = i / L;
     const float hs = 0.5f * expf(0.5f * heads[b * ldh + L + l]);
-    float sm = 0.f, sl = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float g = dz[(b * K + k) * lddz + l];
-        sm += g;
-        if (eps) sl += g * eps[(b * K + k) * L + l] * hs;
+    // four replicas in flight (a serial walk over K = 20 was 20 dependent round trips: 9 us at batch 128); fixed association
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+        float g[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] = dz[(b * K + k + u) * lddz + l];
+            e[u] = eps ? eps[(b * K + k + u) * L + l] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sm[u] += g[u]; sl[u] += g[u] * e[u] * hs; }
     }
-    out[b * ldo + l] = sm + (g_heads ? g_heads[b * ldg + l] : 0.f);
-    out[b * ldo + L + l] = sl + (g_heads ? g_heads[b * ldg + L + l] : 0.f);
+    for (; k < K; ++k) {
+        const float g = dz[(b * K + k) * lddz + l];
+        sm[0] += g;
+        if (eps) sl[0] += g * eps[(b * K + k) * L + l] * hs;
+    }
+    const float tm = (sm[0] + sm[1]) + (sm[2] + sm[3]), tl = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+    out[b * ldo + l] = tm + (g_heads ? g_heads[b * ldg + l] : 0.f);
+    out[b * ldo + L + l] = tl + (g_heads ? g_heads[b * ldg + L + l] : 0.f);
 }
 // out = x * mask  (encoder input, VAE.py:2379 / :2750)
 __global__ void nm_mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ o, long n) {

@@ -235,13 +235,24 @@ __device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
                  a2 > 0.f ? dy[2] : dy[2] * (a2 + 1.f), a3 > 0.f ? dy[3] : dy[3] * (a3 + 1.f)};
 }
 
-// sum over the 16 lanes of a DPP row (the 16 batch rows of a lane group): every lane gets it (first half of wave_sum_dpp)
+// sum over the 16 lanes of a DPP row (the 16 batch rows of a lane group): every lane gets it.  The DPP operand is written as part of
+// the add (v_add_f32_dpp) - through the update_dpp builtin hipcc emitted a v_mov_b32_dpp AND an add per step, 256 extra VALU
+// instructions per q tile.
 __device__ __forceinline__ float row_sum_dpp(float v) {
-    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);  // row_half_mirror
-    v += dpp_mov<0x140>(v);  // row_mirror
-    return v;
+    float t;
+    // (s_nop 1 in front of every DPP read: a VGPR written by the previous VALU instruction needs two wait states before a DPP
+    // operand may read it, and the hazard recogniser does not look inside inline assembly)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(t)
+        : "v"(v));
+    return t;
 }
 
 #ifdef VPC_ABLATE
