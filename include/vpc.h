@@ -409,6 +409,19 @@ int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_im
                        const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
                        const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar, float* partE,
                        float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L, void* stream);
+/* vpc_draw_step + vpc_step_small_f32 in ONE launch: every workgroup draws the mask_p bytes (mask[1] = mask_in & keep; mask_in NULL:
+ * none - vanilla_VAE) and the normals of ITS 16 rows (eps_out = eps[0], planes [B][16]: eps[1] and eps_ml follow it, n_eps floats
+ * in all) with the Philox counters vpc_draw_step would use - seed, offsets, state, mask_elem_lo and the eps_* shard description
+ * (eps_pitch 16, eps_rows_local = B) as there -, stores them where the step reads them, and runs the step: the same draws
+ * (train.py:53-55, VAE.py:389-392), one launch less at the batch sizes where a launch is a fifth of the step. */
+int vpc_step_small_draw_f32(const float* x, const float* enc_img, const float* dec_img, int npass, const uint8_t* const* mask,
+                            const uint8_t* const* maskB, const float* cA, const float* cE, const float* const* eps,
+                            const float* eps_ml, float bq, float bp, float cr, float wml, float inv_B, float x_logvar,
+                            float* partE, float* partD, double* loss_partials, int* nblocks_out, long B, int d, int L,
+                            const uint8_t* mask_in, float keep_prob, float* eps_out, long n_eps, unsigned long long seed,
+                            unsigned long long offset_mask, unsigned long long offset_eps, const long long* state,
+                            long mask_elem_lo, long eps_rows_local, long eps_rows_global, long eps_row_lo, int eps_pitch,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,8 @@ _PROTOS = {
     "vpc_pack_weights_bf16": [P, P, P, I, P],
     "vpc_step_small_max_rows": [],
     "vpc_step_small_f32": [P, P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, P, F, F, F, F, F, F, P, P, P, IP, L_, I, I, P],
+    "vpc_step_small_draw_f32": [P, P, P, I, PP, PP, C.POINTER(F), C.POINTER(F), PP, P, F, F, F, F, F, F, P, P, P, IP, L_, I, I,
+                                P, F, P, L_, ULL, ULL, ULL, P, L_, L_, L_, L_, I, P],
     "vpc_step_fused_applicable": [L_, I, I, I],
     "vpc_step_layout_bf16": [I, I, IP, IP],
     "vpc_step_build_indices_bf16": [I, I, P, P],

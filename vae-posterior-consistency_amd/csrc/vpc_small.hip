@@ -20,6 +20,7 @@
 // partial blocks are what vpc_reduce_step(_adam) expects).
 #include "vpc_abi_internal.h"
 #include "vpc_device.h"
+#include "vpc_rng.h"
 #include "vpc_dec_args.h"
 
 namespace vpc {
@@ -45,6 +46,16 @@ struct SmallArgs {
     float bq, bp, cr, wml, inv_B, x_logvar;
     long B;
     int d, L, npass, ntiles;
+    // optional in-kernel draws of the step (vpc_step_small_draw_f32): the workgroup draws the mask_p bytes and the eps values of ITS
+    // 16 rows with the counters vpc_draw_step would use, stores them where the step reads them (m[1], eps[...]) and goes on
+    int draw;                    // 0: inputs are given; 1: draw eps (and mask_p when mask_in != NULL)
+    const uint8_t* mask_in;      // mask that mask_p thins (NULL: no mask draw - vanilla_VAE)
+    float keep_prob;
+    float* eps_out; long n_eps;  // [planes][B][16] planes of normals, n_eps floats in all
+    unsigned long long seed, off_mask, off_eps;
+    const long long* state;
+    long mask_elem_lo;
+    EpsShard shard;
 };
 
 // C-layout tile <-> [row][feature] buffer
@@ -128,6 +139,26 @@ __global__ __launch_bounds__(THREADS) void step_small_kernel(SmallArgs a) {
     for (int t = 0; t < H2T; ++t) acc5[t] = zero4();
     float S_A0 = 0.f, S_E0 = 0.f, S_A1 = 0.f, S_kl0q = 0.f, S_kl0p = 0.f, S_klr = 0.f, S_zll = 0.f;
 
+    if (a.draw) {
+        // ---- the step's draws for this tile's rows (same Philox counters and values as vpc_draw_step: vpc_rng.h)
+        const long row0 = (long)blockIdx.x * 16;
+        const long nrow = a.B - row0 < 16 ? a.B - row0 : 16;
+        uint64_t off_m = a.off_mask, off_e = a.off_eps;
+        if (a.state) { off_m += (uint64_t)a.state[1]; off_e += (uint64_t)a.state[1]; }
+        if (a.mask_in) {  // mask_p bytes [row0 d, (row0 + nrow) d): every 8-byte Philox group that touches them (a group on a
+                          // tile boundary is written by both neighbours - the same bytes)
+            const long lo = row0 * a.d + (a.mask_elem_lo & 7), hi = (row0 + nrow) * a.d + (a.mask_elem_lo & 7);
+            const long g0 = lo / MASK_PER_CALL, g1 = (hi + MASK_PER_CALL - 1) / MASK_PER_CALL;
+            for (long g = g0 + threadIdx.x; g < g1; g += THREADS)
+                draw_mask_body(a.mask_in, const_cast<uint8_t*>(a.m[1]), a.B * (long)a.d, a.keep_prob, a.seed, off_m, g, a.mask_elem_lo);
+        }
+        const long plane = a.B * 16, nplanes = a.n_eps / plane;
+        for (long i = threadIdx.x; i < nplanes * nrow * 4; i += THREADS) {  // 4 groups of 4 normals per row and plane
+            const long pl = i / (nrow * 4), rem = i - pl * nrow * 4;
+            fill_normal_body(a.eps_out, a.n_eps, a.seed, off_e, (pl * plane + row0 * 16) / 4 + rem, a.shard);
+        }
+        __syncthreads();  // (a fence: the stores above are visible to the loads below)
+    }
     {
         const int tile = blockIdx.x;
         const long row0 = (long)tile * 16;
@@ -475,11 +506,16 @@ extern "C" long vpc_step_small_max_rows(void) {
     return lim;
 }
 
-extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_img, int npass,
-                                  const uint8_t* const* mask, const uint8_t* const* maskB, const float* cA, const float* cE,
-                                  const float* const* eps, const float* eps_ml, float bq, float bp, float cr, float wml,
-                                  float inv_B, float x_logvar, float* partE, float* partD, double* loss_partials,
-                                  int* nblocks_out, long B, int d, int L, void* stream) {
+namespace vpc {
+struct SmallDraw {
+    int on; const uint8_t* mask_in; float keep_prob; float* eps_out; long n_eps; unsigned long long seed, off_mask, off_eps;
+    const long long* state; long mask_elem_lo; EpsShard shard;
+};
+static int step_small_launch(const float* x, const float* enc_img, const float* dec_img, int npass,
+                             const uint8_t* const* mask, const uint8_t* const* maskB, const float* cA, const float* cE,
+                             const float* const* eps, const float* eps_ml, float bq, float bp, float cr, float wml,
+                             float inv_B, float x_logvar, float* partE, float* partD, double* loss_partials,
+                             int* nblocks_out, long B, int d, int L, const SmallDraw& dr, void* stream) {
     if (!x || !enc_img || !dec_img || !mask || !cA || !cE || !eps || !partE || !partD || !loss_partials) return VPC_ERR_ARG;
     if (npass < 1 || npass > 2 || B <= 0) return VPC_ERR_ARG;
     if (d < 4 || d > MAX_D || d % 4 || L < 1 || L > MAX_L) return VPC_ERR_SHAPE;
@@ -498,6 +534,17 @@ extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const fl
     for (int p = 0; p < npass; ++p)  // the second loss mask of a pass must be the other pass's mask (as vpc_step_fused_bf16)
         if (a.mB[p] && (npass != 2 || a.mB[p] != a.m[1 - p])) return VPC_ERR_ARG;
     if ((B + 15) / 16 > 2L * num_cus()) return VPC_ERR_SHAPE;  // one workgroup per 16-row tile, at most 2 x CUs partial blocks
+    if (dr.on) {
+        // eps_out must be the planes the step reads: plane p = eps[p] (and eps_ml the next one), [B][16] each
+        if (!dr.eps_out || dr.n_eps < B * 16 || dr.n_eps % (B * 16) || dr.eps_out != eps[0]) return VPC_ERR_ARG;
+        if (npass == 2 && (eps[1] != dr.eps_out + B * 16 || dr.n_eps < 2 * B * 16)) return VPC_ERR_ARG;
+        if (eps_ml && (eps_ml != dr.eps_out + 2 * B * 16 || dr.n_eps < 3 * B * 16)) return VPC_ERR_ARG;
+        if (dr.mask_in && npass != 2) return VPC_ERR_ARG;
+        if (dr.mask_elem_lo < 0) return VPC_ERR_ARG;
+        a.draw = 1; a.mask_in = dr.mask_in; a.keep_prob = dr.keep_prob; a.eps_out = dr.eps_out; a.n_eps = dr.n_eps;
+        a.seed = dr.seed; a.off_mask = dr.off_mask; a.off_eps = dr.off_eps; a.state = dr.state;
+        a.mask_elem_lo = dr.mask_elem_lo; a.shard = dr.shard;
+    }
     a.ntiles = (int)((B + 15) / 16);
     const int grid = a.ntiles;
     if (nblocks_out) *nblocks_out = grid;
@@ -512,4 +559,35 @@ extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const fl
     switch (dt_for(d)) { VPC_CASE(1) VPC_CASE(2) VPC_CASE(4) VPC_CASE(8) }
 #undef VPC_CASE
     return VPC_ERR_SHAPE;
+}
+}  // namespace vpc
+
+extern "C" int vpc_step_small_f32(const float* x, const float* enc_img, const float* dec_img, int npass,
+                                  const uint8_t* const* mask, const uint8_t* const* maskB, const float* cA, const float* cE,
+                                  const float* const* eps, const float* eps_ml, float bq, float bp, float cr, float wml,
+                                  float inv_B, float x_logvar, float* partE, float* partD, double* loss_partials,
+                                  int* nblocks_out, long B, int d, int L, void* stream) {
+    return step_small_launch(x, enc_img, dec_img, npass, mask, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE,
+                             partD, loss_partials, nblocks_out, B, d, L, SmallDraw{}, stream);
+}
+
+// vpc_draw_step + vpc_step_small_f32 in ONE launch: every workgroup draws the mask_p bytes (mask[1] = mask_in & keep, when mask_in !=
+// NULL) and the normals of ITS 16 rows - eps_out = eps[0], planes [B][16]: eps[1] and eps_ml follow it; n_eps floats in all - with the
+// Philox counters vpc_draw_step would use (seed, offsets, state, mask_elem_lo and the eps_* shard description as there), stores them
+// where the step reads them, and runs the step.  Same draws, one launch less at the batch sizes where a launch is a fifth of the step.
+extern "C" int vpc_step_small_draw_f32(const float* x, const float* enc_img, const float* dec_img, int npass,
+                                       const uint8_t* const* mask, const uint8_t* const* maskB, const float* cA, const float* cE,
+                                       const float* const* eps, const float* eps_ml, float bq, float bp, float cr, float wml,
+                                       float inv_B, float x_logvar, float* partE, float* partD, double* loss_partials,
+                                       int* nblocks_out, long B, int d, int L, const uint8_t* mask_in, float keep_prob,
+                                       float* eps_out, long n_eps, unsigned long long seed, unsigned long long offset_mask,
+                                       unsigned long long offset_eps, const long long* state, long mask_elem_lo,
+                                       long eps_rows_local, long eps_rows_global, long eps_row_lo, int eps_pitch, void* stream) {
+    if (eps_rows_local < 0 || (eps_rows_local > 0 && (eps_pitch != 16 || eps_rows_local != B || eps_row_lo < 0 ||
+                                                      eps_row_lo + eps_rows_local > eps_rows_global)))
+        return VPC_ERR_ARG;
+    SmallDraw dr{1, mask_in, keep_prob, eps_out, n_eps, seed, offset_mask, offset_eps, state, mask_elem_lo,
+                 EpsShard{eps_rows_local, eps_rows_global, eps_row_lo, eps_pitch}};
+    return step_small_launch(x, enc_img, dec_img, npass, mask, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE,
+                             partD, loss_partials, nblocks_out, B, d, L, dr, stream);
 }

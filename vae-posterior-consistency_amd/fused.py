@@ -234,7 +234,21 @@ class FusedTrainer:
         # counters advance by what the GLOBAL batch consumes, so that all ranks stay on one stream of counters
         n_eps_groups = eps_view.shape[0] * Bg * (LP // 4)
         eps_shard = (B, Bg, row_lo, LP)
-        if two and mask_p is None:
+        # small batches: the N-split kernel makes the step's draws itself (same counters, one launch less) when ALL of them are
+        # drawn on the device
+        all_dev = eps_q is None and (not two or eps_p is None) and (not need_ml or eps_ml is None)
+        fuse_draw = use_small and all_dev and (not two or mask_p is None) and LP == 16
+        draw_args = None
+        if fuse_draw:
+            off_m = self.rng_offset
+            if two:
+                self.rng_offset += (Bg * dk + 7) // 8 + 1
+                mask_p = self.mask_p_buf
+            draw_args = (mask if two else None, 1.0 - p_missingness / 100.0, eps_view, self.seed, off_m, self.rng_offset, _state,
+                         row_lo * dk, eps_shard)
+            self.rng_offset += n_eps_groups
+            draw_eps = False
+        elif two and mask_p is None:
             off_m = self.rng_offset
             self.rng_offset += (Bg * dk + 7) // 8 + 1
             if draw_eps:
@@ -265,9 +279,14 @@ class FusedTrainer:
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * len(masks)
         if use_small:
             # ---- small batch (fp32 arithmetic in every precision): the whole step in ONE launch, 16-row tiles with the feature tiles split over the waves
-            nbE = nbD = self._timed("step_small", ops.step_small_f32, x, enc_img, dec_img, masks, maskB, co["cA"], co["cE"], epss,
-                                    eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, self.partE,
-                                    self.partD, self.loss_part, dk, Ld)
+            if draw_args is not None:
+                nbE = nbD = self._timed("step_small", ops.step_small_draw_f32, x, enc_img, dec_img, masks, maskB, co["cA"],
+                                        co["cE"], epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
+                                        self.partE, self.partD, self.loss_part, dk, Ld, *draw_args)
+            else:
+                nbE = nbD = self._timed("step_small", ops.step_small_f32, x, enc_img, dec_img, masks, maskB, co["cA"], co["cE"],
+                                        epss, eml, co["bq"], co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value,
+                                        self.partE, self.partD, self.loss_part, dk, Ld)
         elif use_step:
             # ---- plain bf16, throughput shape: encoder forward + decoder + loss + all backward in ONE launch
             nbE = nbD = self._timed("step_fused", ops.step_fused_bf16, x, self.img_c, masks, maskB, co["cA"], co["cE"], epss,

@@ -137,6 +137,22 @@ def step_small_f32(x, enc_img, dec_img, masks, maskB, cA, cE, eps, eps_ml, bq, b
     return nb.value
 
 
+def step_small_draw_f32(x, enc_img, dec_img, masks, maskB, cA, cE, eps, eps_ml, bq, bp, cr, wml, inv_B, x_logvar, partE, partD,
+                        loss_part, d, Ld, mask_in, keep_prob, eps_out, seed, offset_mask, offset_eps, state=None, elem_lo=0,
+                        eps_shard=None):
+    """step_small_f32 that also makes the step's draws (mask_p = mask_in & keep into masks[1], eps into eps_out = eps[0]...)
+    inside the same launch, with vpc_draw_step's counters."""
+    n = len(masks)
+    nb = C.c_int(0)
+    check(lib().vpc_step_small_draw_f32(ptr(x), ptr(enc_img), ptr(dec_img), n, ptr_array(masks), ptr_array(maskB), farray(cA),
+                                        farray(cE), ptr_array(eps), ptr(eps_ml), bq, bp, cr, wml, inv_B, x_logvar, ptr(partE),
+                                        ptr(partD), ptr(loss_part), C.byref(nb), x.shape[0], d, Ld, ptr(mask_in),
+                                        float(keep_prob), ptr(eps_out), eps_out.numel(), int(seed), int(offset_mask),
+                                        int(offset_eps), ptr(state), int(elem_lo), *_shard4(eps_shard), stream_ptr()),
+          "vpc_step_small_draw_f32")
+    return nb.value
+
+
 def step_fused_applicable(B, d, Ld, npass):
     return bool(lib().vpc_step_fused_applicable(int(B), d, Ld, npass))
 
