@@ -423,6 +423,14 @@ class _NMBase(nn.Module):
         return out
 
     def _views(self):
+        # fast path (every training step): the flat buffer and the cached views are current when the first and the last parameter
+        # still sit where the flat buffer has them - `.to()` / re-assignment moves all 18, in-place loads keep them (the full
+        # check of flatten_parameters walks every parameter: ~12 us of a host-paced 0.19 ms step)
+        vc = getattr(self, "_view_cache", None)
+        flat = self._flat
+        if vc is not None and flat is not None and vc[0] is flat and self.W.data.data_ptr() == flat.data_ptr() and \
+                self.x_logvar[0].bias.data.data_ptr() == flat.data_ptr() + 4 * (flat.numel() - self.obs_dim):
+            return vc[1]
         flat = self.flatten_parameters()
         L.require_cuda(flat)
         if getattr(self, "_view_cache", None) is None or self._view_cache[0] is not flat:
@@ -621,6 +629,14 @@ class NMTrainer:
             o += n
         nbytes = int(lib().vpc_nm_loss_scratch(B, d))
         self.scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+        # the slices the step passes to its launches, made once per batch size (a tensor view costs 1-3 us of host time, and the
+        # eager step at the reference's batch 128 is paced by the host)
+        BK = B * K
+        Y, G = self.Y, self.G
+        self._sl = dict(Yl=Y[:, d:], Yp=Y[BK:] if self.reg else None, Ypl=Y[BK:, d:] if self.reg else None, Gl=G[:, d:],
+                        Gp=G[BK:] if self.reg else None, Gpl=G[BK:, d:] if self.reg else None,
+                        hp=self.heads[B:] if self.reg else None, ghp=self.gheads[B:] if self.reg else None,
+                        eps0=self.eps[0], eps1=self.eps[1])
         if self.use_nmdec:  # image, partial blocks, index tables
             nimg, npart, nblk = C.c_int(), C.c_long(), C.c_int()
             check(lib().vpc_nmdec_layout(B, K, d, Ld, C.byref(nimg), C.byref(npart), C.byref(nblk)), "vpc_nmdec_layout")
@@ -735,15 +751,16 @@ class NMTrainer:
         d, Ld, K = m.obs_dim, m.latent_dim, m.num_samples
         P = 2 if reg else 1
         R, M, BK = P * B, P * B * K, B * K
-        t("sample", nm_sample, self.heads, self.eps if reg else self.eps[0], self.z, R, K, Ld)
+        sl = self._sl
+        t("sample", nm_sample, self.heads, self.eps if reg else sl["eps0"], self.z, R, K, Ld)
         t("dec_fwd1", linear_fwd, self.z, v["Wd1"], v["bd1"], self.g1, M, HID, Ld, ACT_ELU, precision=self.prec)
         t("dec_fwd2", linear_fwd, self.g1, v["Wd2"], v["bd2"], self.g2, M, HID, HID, ACT_ELU, precision=self.prec)
         t("dec_fwd3", linear_fwd, self.g2, v["Wx"], v["bx"], self.Y, M, 2 * d, HID, ACT_SIGMOID_HARDTANH, d, precision=self.prec)
         # ---- loss + output-side gradients
         Y, G = self.Y, self.G
-        t("loss", nm_loss, xf, mf, mp, Y, Y[:, d:], 2 * d, Y[BK:] if reg else None, Y[BK:, d:] if reg else None, 2 * d,
-          self.heads, self.heads[B:] if reg else None, v["W"], v["b"], None if reg else self.eps[1], G, G[:, d:],
-          G[BK:] if reg else None, G[BK:, d:] if reg else None, 2 * d, self.gheads, self.gheads[B:] if reg else None,
+        t("loss", nm_loss, xf, mf, mp, Y, sl["Yl"], 2 * d, sl["Yp"], sl["Ypl"], 2 * d,
+          self.heads, sl["hp"], v["W"], v["b"], None if reg else sl["eps1"], G, sl["Gl"],
+          sl["Gp"], sl["Gpl"], 2 * d, self.gheads, sl["ghp"],
           self.g["W"], self.g["b"], None, self.scratch, self.out8, self.loss,
           self.accum if self.world_size == 1 else None,  # data parallel: the epoch total takes the ALL-REDUCED loss (below)
           B, Bg, K, d, Ld, alpha, _state, rng_inc, True)
@@ -755,7 +772,7 @@ class NMTrainer:
         t("dec_dgrad2", linear_dgrad, self.dg2, v["Wd2"], self.dg1, M, HID, HID, x_out=self.g1, act_prev=ACT_ELU, precision=self.prec)
         wgrad("dec_wgrad1", 2, self.dg1, self.z, g["Wd1"], g["bd1"])
         t("dec_dgrad1", linear_dgrad, self.dg1, v["Wd1"], self.dz, M, HID, Ld, precision=self.prec)
-        t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else self.eps[0], self.heads, self.gheads, self.dht, R,
+        t("sample_bwd", nm_sample_bwd, self.dz, self.eps if reg else sl["eps0"], self.heads, self.gheads, self.dht, R,
           K, Ld)
 
     def step_graph(self, x, mask, *, alpha=1.0, p_missingness=30):
