@@ -259,6 +259,7 @@ class EDDITrainer:
         self.n_trunk = sum(p.numel() for p in model.trainable()[:6])
         self.n_dec = self.lay.n_params - self.lay.n_enc
         self._B = None
+        self._flat_dec = None
 
     def _ws(self, B):
         if self._B == B:
@@ -280,6 +281,14 @@ class EDDITrainer:
         self.wg_shapes = [(R, 2 * m.latent_dim, H2), (R, H2, H1), (R, H1, K)]
         self.wg_scratch = [e(int(lib().vpc_linear_wgrad_scratch(*sh))) for sh in self.wg_shapes]
         self._wg_cache = {}
+        # the slices the step passes to its launches, made once per batch size (1-3 us of host time each; the step is host-paced)
+        self._sl = dict(mean=[self.lat[p_, 0] for p_ in range(P)], logvar=[self.lat[p_, 1] for p_ in range(P)],
+                        dmean=[self.dlat[p_, 0] for p_ in range(P)], dlogvar=[self.dlat[p_, 1] for p_ in range(P)],
+                        eps=[self.eps_buf[p_] for p_ in range(3)], lat_dst=self.lat[..., :Ld],
+                        heads_src=self.heads.view(P, B, 2, Ld).permute(0, 2, 1, 3), dheads_dst=self.dheads.view(P, B, 2, Ld),
+                        dlat_src=self.dlat[..., :Ld].permute(0, 2, 1, 3),
+                        gdec=self.grad[self.n_trunk:self.n_trunk + self.n_dec], gidx_dec=self.gidx[self.lay.n_enc:],
+                        pidx_dec=self.pidx[self.lay.n_enc:])
         self._B = B
 
     def step(self, x, mask, mask_p=None, eps_q=None, eps_p=None, eps_ml=None, *, epoch=1, alpha=0.5, beta=1.0,
@@ -335,25 +344,22 @@ class EDDITrainer:
         linear_fwd(self.agg, W1, b1, self.h1, R, H1, K, ACT_RELU)
         linear_fwd(self.h1, W2, b2, self.h2, R, H2, H1, ACT_RELU)
         linear_fwd(self.h2, W3, b3, self.heads, R, 2 * Ld, H2, ACT_NONE)
-        self.lat[..., :Ld].copy_(self.heads.view(P, B, 2, Ld).permute(0, 2, 1, 3))
-        mean = [self.lat[p_, 0] for p_ in range(P)]
-        logvar = [self.lat[p_, 1] for p_ in range(P)]
-        dmean = [self.dlat[p_, 0] for p_ in range(P)]
-        dlogvar = [self.dlat[p_, 1] for p_ in range(P)]
-        epss = [self.eps_buf[p_] for p_ in range(P)]
-        eml = self.eps_buf[2] if need_ml else None
+        sl = self._sl
+        sl["lat_dst"].copy_(sl["heads_src"])
+        mean, logvar, dmean, dlogvar = sl["mean"], sl["logvar"], sl["dmean"], sl["dlogvar"]
+        epss = sl["eps"][:P]
+        eml = sl["eps"][2] if need_ml else None
         # ---- fused decoder + loss + decoder backward (the VAE step's kernel)
         maskB = [mask_p, None] if (two and co["cE"][0] != 0.0) else [None] * P
         nbD = ops.decoder_fused(x, dec_img, masks, maskB, co["cA"], co["cE"], mean, logvar, epss, eml, co["bq"],
                                 co["bp"], co["cr"], co["wml"], 1.0 / Bg, m._x_logvar_value, dmean, dlogvar, self.partD,
                                 self.loss_part, d, Ld, LP)
-        gdec = self.grad[self.n_trunk:self.n_trunk + self.n_dec]
-        ops.reduce_partials(self.partD, nbD, lay.dec_part, self.gidx[lay.n_enc:], gdec)
+        ops.reduce_partials(self.partD, nbD, lay.dec_part, sl["gidx_dec"], sl["gdec"])
         cA1 = co["cA"][1] if two else 0.0
         ops.loss_finalize(self.loss_part, nbD, co["cA"][0], co["cE"][0], cA1, co["bq"], co["bp"], co["cr"], co["wml"], B,
                           Bg, d, self.out9, self.accum if self.world_size == 1 else None)
         # ---- encoder backward
-        self.dheads.view(P, B, 2, Ld).copy_(self.dlat[..., :Ld].permute(0, 2, 1, 3))
+        sl["dheads_dst"].copy_(sl["dlat_src"])
         g = self.g
         # (the three weight gradients leave their GEMMs as partials and are summed by ONE launch: two launches less per step)
         sc = self.wg_scratch
@@ -378,7 +384,9 @@ class EDDITrainer:
         ops.adam_step(m._flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
                       self.betas[1], self.eps, loss_in=self.out9 if dp else None, accum=self.accum if dp else None)
         # keep the packed decoder image in step with the parameters (the version check would re-pack it anyway)
-        ops.pack_weights(m._flat[self.n_trunk:self.n_trunk + self.n_dec], self.pidx[lay.n_enc:], m._img)
+        if self._flat_dec is None or self._flat_dec[0] is not m._flat:
+            self._flat_dec = (m._flat, m._flat[self.n_trunk:self.n_trunk + self.n_dec])
+        ops.pack_weights(self._flat_dec[1], sl["pidx_dec"], m._img)
         m._img_version = m._versions()
 
     def loss_value(self) -> float:
