@@ -126,6 +126,7 @@ __device__ __forceinline__ void nd_layer_fwd(const float* W, const Op (&in)[KB],
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag<KP>(W, mt + 2, kb, m, q); c1[kb] = nd_wfrag<KP>(W, mt + 3, kb, m, q); }
         }
+        asm volatile("" : "+v"(a0), "+v"(a1));
         __builtin_amdgcn_sched_barrier(0);
         sink(mt, a0, a1);
     }
@@ -199,6 +200,7 @@ __device__ __forceinline__ void nd_heads(const float* W, const Op (&in)[4], int 
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) { c0[kb] = nd_wfrag<128>(W, t + 1, kb, m, q); c1[kb] = nd_wfrag<128>(W, DT + t + 1, kb, m, q); }
         }
+        asm volatile("" : "+v"(a0), "+v"(a1));
         __builtin_amdgcn_sched_barrier(0);
         sink(t, a0, a1);
         __builtin_amdgcn_sched_barrier(0);
