@@ -290,10 +290,6 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     constexpr int YT = 2 * DT;  // head tiles: xm 0 .. DT - 1, xl DT .. 2 DT - 1
 
     // the lane's row inside a tile: replica k of tile-local data row bl
-    const int r0 = 16 * w + c;
-    const int bl = r0 / K, k = r0 - bl * K;
-    const bool rvalid = r0 < a.nb * K;
-    const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's inputs and l_w; their weights are zero)
     const int KP4 = (K + 3) & ~3;
 
     // Column sums over the rows (the three bias gradients, dW | db of the missingness model) come from the same staged operands as
@@ -413,7 +409,12 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
         launder(cc, qq);
-        const int r = 16 * w + cc;  // (from the laundered lane id: what hangs off it is re-derived per tile, not kept across the loop)
+        // the lane's row inside the tile: replica k of tile-local data row bl - re-derived per tile from the laundered lane id (kept
+        // across the loop these live in scratch)
+        const int r = 16 * w + cc;
+        const int bl = r / K, k = r - bl * K;
+        const bool rvalid = r < a.nb * K;
+        const int blc = rvalid ? bl : 0;  // (padding rows read the first data row's inputs and l_w; their weights are zero)
         const int pass = tile / a.tiles_per_pass;
         const bool qpass = pass == 0;
         const int b0 = (tile - pass * a.tiles_per_pass) * a.nb;
