@@ -333,7 +333,7 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
  *   vpc_nmdec_layout         floats of the weight image, floats of one partial block, most workgroups of a launch
  *   vpc_nmdec_build_indices  HOST tables over the model's flat parameter buffer (n entries, order
  *                            [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]): pack_idx as
- *                            vpc_step_pack_weights_bf16 reads it (INT_MIN: not in the image - the encoder), grad_idx =
+ *                            vpc_step_pack_weights_bf16 reads it (decoder + missingness model, then the encoder), grad_idx =
  *                            position of the parameter's gradient inside a partial block (-1: not produced here)
  *   vpc_nmdec_step           mask_p != NULL (REG_notMIWAE_v2): heads [2 B][ldh] = encoder (mean | logvar) of the q rows, then
  *                            of the p rows; eps [2 B K][L] likewise.  mask_p == NULL (notMIWAE_myversion): heads [B][ldh],
@@ -347,6 +347,11 @@ int vpc_nm_prep(const float* x, const float* mask, float* mask_p_out, float* xin
 int vpc_nmdec_applicable(long B, int K, int d, int L);
 int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks);
 int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n);
+/* the encoder forward of the same step (seq_encoder + q_mu | q_logstd, VAE.py:2378-2384 / :2749-2756) as ONE launch instead of three
+ * vpc_linear_fwd: xin [R][128] = x * mask of the stacked passes -> h1, h2 [R][128] (fp32, ELU applied: the backward GEMMs read them),
+ * heads [R][2 L]; img = the image buffer vpc_nmdec_layout sizes and vpc_nmdec_build_indices' pack_idx fills (the encoder's weights sit
+ * behind the decoder's).  Rounding points of vpc_linear_fwd with precision 2. */
+int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, float* heads, long R, int d, int L, void* stream);
 int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
                    const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx,
                    float* grad, int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,

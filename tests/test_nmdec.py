@@ -41,14 +41,18 @@ def test_index_tables_cpu():
     nimg, npart, nblk = C.c_int(), C.c_long(), C.c_int()
     assert _lib.lib().vpc_nmdec_layout(128, 20, d, L, C.byref(nimg), C.byref(npart), C.byref(nblk)) == 0
     enc = slice(2 * d, 2 * d + n_enc)
-    assert (pidx[enc] == INT_MIN).all() and (gidx[enc] == -1).all()
+    assert (gidx[enc] == -1).all()  # the encoder's gradients come from the GEMM chain
     own = np.r_[0:2 * d, 2 * d + n_enc:2 * d + n_enc + n_dec]
-    p, g = pidx[own].astype(np.int64), gidx[own].astype(np.int64)
-    assert (p != INT_MIN).all() and (g >= 0).all()
-    # bf16 entries: u16 positions inside the image; fp32 entries: dword -(idx + 1); no two parameters share a place
+    g = gidx[own].astype(np.int64)
+    assert (g >= 0).all()
+    # every parameter has its own place in the image: bf16 entries = u16 positions, fp32 entries = dword -(idx + 1); the
+    # encoder's (read by vpc_nmenc_fwd) sit behind the decoder kernel's part
+    p = pidx.astype(np.int64)
+    assert (p != INT_MIN).all()
     u16 = p[p >= 0]
     f32 = -(p[p < 0] + 1)
-    assert len(u16) == HID * L + HID * HID + 2 * d * HID and len(f32) == 2 * d + 2 * HID + 2 * d
+    n_w = HID * L + HID * HID + 2 * d * HID + HID * d + HID * HID + 2 * L * HID
+    assert len(u16) == n_w and len(f32) == len(p) - n_w
     assert u16.max() < 2 * nimg.value and f32.max() < nimg.value
     assert len(np.unique(u16)) == len(u16) and len(np.unique(f32)) == len(f32)
     assert not np.intersect1d(u16 // 2, f32).size

@@ -833,6 +833,79 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ encoder forward
+// The encoder of the same step (seq_encoder + the two heads, VAE.py:2378-2384 / :2749-2756) as ONE launch instead of three GEMMs:
+// d = 128 -> 128 (ELU) -> 128 (ELU) -> (mean | logvar), a 16-row tile per wave, register-chained on the bf16 MFMA with its weights
+// in LDS (72 KB: compact images of We1, We2, Wh behind the decoder's in the same image buffer, packed by the same launch).  Same
+// rounding points as vpc_linear_fwd with precision 2 (bf16 operands, fp32 bias and accumulation); h1 / h2 leave as fp32 - the
+// backward GEMMs read them.  At the reference's batch 128 (256 stacked rows) three dependent 5.5 us launches become one.
+struct NeImg {
+    static constexpr int oW1 = 0, oW2 = oW1 + ND_HID * 64, oWh = oW2 + ND_HID * 64, ob1 = oWh + 32 * 64, ob2 = ob1 + ND_HID,
+                         obh = ob2 + ND_HID, total = obh + 32;
+};
+constexpr int NE_LDS = NeImg::total * 4;
+struct NmeArgs {
+    const float* img;   // encoder part of the image buffer
+    const float* xin;   // [R][128] = x * mask of the stacked passes
+    float* h1; float* h2; float* heads;  // [R][128], [R][128], [R][2 L]
+    long R; int L;
+};
+__global__ __launch_bounds__(ND_THREADS) void nmenc_fwd_kernel(NmeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    load_image<19>(lds, a.img, NeImg::total);
+    __syncthreads();
+    const float* W1 = lds + NeImg::oW1;
+    const float* W2 = lds + NeImg::oW2;
+    const float* Wh = lds + NeImg::oWh;
+    const float* b1 = lds + NeImg::ob1;
+    const float* b2 = lds + NeImg::ob2;
+    const float* bh = lds + NeImg::obh;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const long ntiles = (a.R + 15) / 16;
+    for (long tile = (long)blockIdx.x * ND_WAVES + w; tile < ntiles; tile += (long)gridDim.x * ND_WAVES) {
+        const long row = tile * 16 + c;
+        const bool ok = row < a.R;
+        const long rc = ok ? row : a.R - 1;
+        Op xb[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.xin + rc * 128 + 32 * kb + 4 * q);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(a.xin + rc * 128 + 32 * kb + 16 + 4 * q);
+            xb[kb] = nd_pack2(t0, t1);
+        }
+        Op h1b[4], h2b[4];
+        nd_layer_fwd<128, 4, ND_HT>(W1, xb, c, q, [&](int mt, f32x4 a0, f32x4 a1) {
+            const f32x4 v0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * q));
+            const f32x4 v1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 16 + 4 * q));
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.h1 + row * 128 + 16 * mt + 4 * q) = v0;
+                *reinterpret_cast<f32x4*>(a.h1 + row * 128 + 16 * mt + 16 + 4 * q) = v1;
+            }
+            h1b[mt >> 1] = nd_pack2(v0, v1);
+        });
+        nd_layer_fwd<128, 4, ND_HT>(W2, h1b, c, q, [&](int mt, f32x4 a0, f32x4 a1) {
+            const f32x4 v0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 4 * q));
+            const f32x4 v1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 16 + 4 * q));
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.h2 + row * 128 + 16 * mt + 4 * q) = v0;
+                *reinterpret_cast<f32x4*>(a.h2 + row * 128 + 16 * mt + 16 + 4 * q) = v1;
+            }
+            h2b[mt >> 1] = nd_pack2(v0, v1);
+        });
+        nd_layer_fwd<128, 4, 2>(Wh, h2b, c, q, [&](int, f32x4 a0, f32x4 a1) {  // out rows 0 .. 2 L - 1 (two 16-row tiles; the rest is 0)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = (h ? a1 : a0) + *reinterpret_cast<const f32x4*>(bh + 16 * h + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = 16 * h + 4 * q + j;
+                    if (ok && o < 2 * a.L) a.heads[row * (2 * a.L) + o] = v[j];
+                }
+            }
+        });
+    }
+}
+
 // fixed-order reduction of the partial blocks into the flat gradient (W | b of the missingness model and the decoder segment)
 // + the loss terms (block 0), as nm_finalize_kernel of vpc_nm.hip
 struct NmdFinArgs {
@@ -936,7 +1009,7 @@ int vpc_nmdec_applicable(long B, int K, int d, int L) {
 // sizes the caller allocates: the image (floats), one partial block (floats) and the most workgroups a launch uses
 int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_floats, int* max_blocks) {  // (max_blocks: of the two-pass form)
     if (B <= 0 || !nmdec_shape_ok(K, d, L)) return VPC_ERR_SHAPE;
-    if (img_floats) *img_floats = NdImg::total;
+    if (img_floats) *img_floats = NdImg::total + NeImg::total;  // the decoder kernel's image, then the encoder forward kernel's
     if (part_floats) *part_floats = ND_PART;
     if (max_blocks) {
         const int nb = ND_ROWS / K;
@@ -949,8 +1022,9 @@ int vpc_nmdec_layout(long B, int K, int d, int L, int* img_floats, long* part_fl
 
 // index tables over the model's flat parameter buffer [W b | We1 be1 We2 be2 Wmu Wls bmu bls | Wd1 bd1 Wd2 bd2 Wxm Wxl bxm bxl]
 // (notmiwae.py _flat_order; n = its length):  pack_idx[i] as vpc_step_pack_weights_bf16 reads it (u16 position inside the image,
-// -(dword + 1) for values that stay fp32, INT_MIN = not in the image: the encoder),  grad_idx[i] = position of parameter i's
-// gradient inside a partial block (-1: the encoder's parameters, whose gradients the GEMM chain writes)
+// -(dword + 1) for values that stay fp32; the encoder's parameters sit behind the decoder kernel's image, for vpc_nmenc_fwd),
+// grad_idx[i] = position of parameter i's gradient inside a partial block (-1: the encoder's parameters, whose gradients the
+// GEMM chain writes)
 int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx, int n) {
     if (hid != ND_HID || !nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
     if (!pack_idx || !grad_idx) return VPC_ERR_ARG;
@@ -967,6 +1041,20 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
         pack_idx[d + f] = -(NdImg::oBm + f + 1);
         grad_idx[f] = pos(R_WB + 2 + g, 0, q, c);
         grad_idx[d + f] = pos(R_WB + g, 0, q, c);
+    }
+    {  // encoder (vpc_nmenc_fwd): We1 be1 We2 be2 [Wmu ; Wls] [bmu ; bls] behind the decoder's image
+        const int e0 = 2 * d, oWe1 = e0, obe1 = oWe1 + hid * d, oWe2 = obe1 + hid, obe2 = oWe2 + hid * hid, oWh = obe2 + hid,
+                  obh = oWh + 2 * L * hid, I0 = NdImg::total;
+        for (int r = 0; r < hid; ++r) {
+            for (int f = 0; f < d; ++f) pack_idx[oWe1 + r * d + f] = 2 * (I0 + NeImg::oW1) + nd_elem<128>(r, f);
+            pack_idx[obe1 + r] = -(I0 + NeImg::ob1 + r + 1);
+            for (int f = 0; f < hid; ++f) pack_idx[oWe2 + r * hid + f] = 2 * (I0 + NeImg::oW2) + nd_elem<128>(r, f);
+            pack_idx[obe2 + r] = -(I0 + NeImg::ob2 + r + 1);
+        }
+        for (int r = 0; r < 2 * L; ++r) {
+            for (int f = 0; f < hid; ++f) pack_idx[oWh + r * hid + f] = 2 * (I0 + NeImg::oWh) + nd_elem<128>(r, f);
+            pack_idx[obh + r] = -(I0 + NeImg::obh + r + 1);
+        }
     }
     int o = 2 * d + n_enc;
     const int oWd1 = o, obd1 = oWd1 + hid * L, oWd2 = obd1 + hid, obd2 = oWd2 + hid * hid, oWx = obd2 + hid,
@@ -1046,6 +1134,22 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
     f.out = out8; f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
     const int fin_grid = 1 + (inv_idx ? (ND_PART / 4 + 7) / 8 : (n + 255) / 256);
     hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(fin_grid), dim3(256), 0, st, f);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// Encoder forward of the stacked passes in one launch (img = the image buffer of vpc_nmdec_build_indices: the encoder's part is
+// behind the decoder's): xin [R][128] -> h1, h2 [R][128] (fp32, ELU applied), heads [R][2 L].  Shapes as vpc_nmdec_step.
+int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, float* heads, long R, int d, int L, void* stream) {
+    if (!img || !xin || !h1 || !h2 || !heads || R <= 0) return VPC_ERR_ARG;
+    if (!nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(xin) | reinterpret_cast<uintptr_t>(h1) |
+         reinterpret_cast<uintptr_t>(h2)) & 15)
+        return VPC_ERR_ARG;
+    NmeArgs a{img + NdImg::total, xin, h1, h2, heads, R, L};
+    const long tiles = (R + 15) / 16, wgs = (tiles + ND_WAVES - 1) / ND_WAVES;
+    const long cap = 2L * num_cus();
+    if (!lds_attr_done(reinterpret_cast<const void*>(nmenc_fwd_kernel), NE_LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(nmenc_fwd_kernel, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(ND_THREADS), NE_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

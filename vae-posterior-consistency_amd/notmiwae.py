@@ -133,6 +133,10 @@ def nmdec_tables(model, device):
     return torch.from_numpy(pidx).to(device), torch.from_numpy(gidx).to(device), torch.from_numpy(inv).to(device)
 
 
+def nmenc_fwd(img, xin, h1, h2, heads, R, d, Ld):
+    check(lib().vpc_nmenc_fwd(ptr(img), ptr(xin), ptr(h1), ptr(h2), ptr(heads), R, d, Ld, stream_ptr()), "vpc_nmenc_fwd")
+
+
 def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, inv, grad, out8, loss_f32, accum, B, B_global, K, d,
                Ld, alpha, state=None, rng_inc=0):
     check(lib().vpc_nmdec_step(ptr(img), ptr(x), ptr(mask), ptr(mask_p), ptr(heads), 2 * Ld, ptr(eps), ptr(dht),
@@ -699,9 +703,16 @@ class NMTrainer:
             self.eps.copy_(eps)
         self.rng_offset += rng_inc
         # ---- forward
-        t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU, precision=self.prec)
-        t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU, precision=self.prec)
-        t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE, precision=self.prec)
+        if self.use_nmdec:
+            # plain bf16 at obs_dim 128: ONE image (decoder, missingness model, encoder) packed by one launch, the encoder forward
+            # as one kernel (csrc/vpc_nmdec.hip: nmenc_fwd_kernel) instead of three GEMM launches
+            from .ops import step_pack_weights_bf16
+            t("pack", step_pack_weights_bf16, m._flat, self._nd_tables[0], self.nd_img)
+            t("enc_fwd", nmenc_fwd, self.nd_img, self.xin, self.h1, self.h2, self.heads, R, d, Ld)
+        else:
+            t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU, precision=self.prec)
+            t("enc_fwd", linear_fwd, self.h1, v["We2"], v["be2"], self.h2, R, HID, HID, ACT_ELU, precision=self.prec)
+            t("enc_fwd", linear_fwd, self.h2, v["Wh"], v["bh"], self.heads, R, 2 * Ld, HID, ACT_NONE, precision=self.prec)
         g = self.g
         # weight gradients: partials per layer, all summed by one launch after the last one (6 reduction launches less;
         # the timer mode keeps the per-layer form so that every entry brackets a complete gradient)
@@ -719,8 +730,6 @@ class NMTrainer:
             # K-fold rsample, decoder, loss, decoder backward and the K-fold sum of dz in ONE kernel (csrc/vpc_nmdec.hip): the
             # decoder / missingness-model gradients land in self.grad, d loss / d heads in self.dht
             pidx, gidx, ginv = self._nd_tables
-            from .ops import step_pack_weights_bf16
-            t("pack", step_pack_weights_bf16, m._flat, pidx, self.nd_img)
             t("dec_fused", nmdec_step, self.nd_img, xf, mf, mp, self.heads, self.eps, self.dht, self.nd_part, self.nd_stat,
               gidx, ginv, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
               _state, rng_inc)
