@@ -352,6 +352,16 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
  * heads [R][2 L]; img = the image buffer vpc_nmdec_layout sizes and vpc_nmdec_build_indices' pack_idx fills (the encoder's weights sit
  * behind the decoder's).  Rounding points of vpc_linear_fwd with precision 2. */
 int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, float* heads, long R, int d, int L, void* stream);
+/* the encoder BACKWARD of the same step (autograd of VAE.py:2378-2384 behind d loss / d heads) as one launch + the fixed-order
+ * reduction of its partial blocks, instead of three vpc_linear_wgrad, two vpc_linear_dgrad and vpc_linear_wgrad_reduce:
+ * dht [R][2 L] (vpc_nmdec_step's), h1 / h2 / xin [R][128] as vpc_nmenc_fwd saw / stored them -> the gradients of We1 be1 We2 be2
+ * [Wmu ; Wls] [bmu ; bls] inside grad (flat, layout of vpc_nmdec_build_indices) at the entries inv_idx names.  Rounding points of the
+ * precision-2 GEMMs (bf16 dY, X, W operands; ELU' from the fp32 h), except that the bias gradients sum the bf16-rounded dY.
+ * part: scratch of part_floats floats, 16-byte aligned - vpc_nmdec_step's partial blocks serve once that call is enqueued.
+ * vpc_nmenc_build_indices: inv_idx [*part_floats ints] = flat parameter index of a block position or -1 (NULL: size query only). */
+int vpc_nmenc_bwd(const float* img, const float* xin, const float* h1, const float* h2, const float* dht, float* part,
+                  long part_floats, const int* inv_idx, float* grad, long R, int d, int L, void* stream);
+int vpc_nmenc_build_indices(int d, int L, int hid, int* inv_idx, long* part_floats, int n);
 int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
                    const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx,
                    float* grad, int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,

@@ -135,9 +135,10 @@ class _EluRoundedGate(torch.autograd.Function):
 class NMTorchPort:
     """Functional restatement over a dict of tensors (keys NM_KEYS).  ``regularised`` selects REG_notMIWAE_v2.
     ``linear``: the affine layer (default F.linear; `rounded_linear("bf16")` models the bf16 GEMM kernels).
-    ``fused_decoder``: model the rounding points of the layer-fused decoder kernel (csrc/vpc_nmdec.hip) on the decoder side:
-    bias gradients from the bf16-rounded dY, ELU' from the bf16-rounded activation (the missingness model's dW / db are fp32
-    row sums there as everywhere; the encoder keeps `linear`: it stays on the GEMM kernels)."""
+    ``fused_decoder``: model the rounding points of the layer-fused kernels (csrc/vpc_nmdec.hip).  Decoder side: bias gradients
+    from the bf16-rounded dY, ELU' from the bf16-rounded activation (the missingness model's dW / db are fp32 row sums there as
+    everywhere).  Encoder side (nmenc_fwd / nmenc_bwd kernels): the bf16 GEMM rounding points, bias gradients from the
+    bf16-rounded dY, ELU' from the fp32 activation (plain F.elu)."""
 
     def __init__(self, params: Dict[str, torch.Tensor], L: int, K: int, regularised: bool, linear=None, fused_decoder=False):
         self.p = params
@@ -146,15 +147,17 @@ class NMTorchPort:
         self.fused_decoder = fused_decoder
         self.lin_dec = rounded_linear("bf16", db_rounded=True) if fused_decoder else self.lin
         self.elu_dec = _EluRoundedGate.apply if fused_decoder else F.elu
+        self.lin_enc = self.lin_dec if fused_decoder else self.lin
 
     # VAE.py:2378-2391 / :2749-2765
     def encoder(self, x, mask, eps: Optional[torch.Tensor]):
         p = self.p
         dt = p["seq_encoder.0.weight"].dtype  # fp32 in the reference (x.float()); float64 only in the oracle self-check
-        h = F.elu(self.lin(x.to(dt) * mask.to(dt), p["seq_encoder.0.weight"], p["seq_encoder.0.bias"]))
-        h = F.elu(self.lin(h, p["seq_encoder.2.weight"], p["seq_encoder.2.bias"]))
-        mean = self.lin(h, p["q_mu.0.weight"], p["q_mu.0.bias"])
-        logvar = self.lin(h, p["q_logstd.0.weight"], p["q_logstd.0.bias"])
+        lin = self.lin_enc
+        h = F.elu(lin(x.to(dt) * mask.to(dt), p["seq_encoder.0.weight"], p["seq_encoder.0.bias"]))
+        h = F.elu(lin(h, p["seq_encoder.2.weight"], p["seq_encoder.2.bias"]))
+        mean = lin(h, p["q_mu.0.weight"], p["q_mu.0.bias"])
+        logvar = lin(h, p["q_logstd.0.weight"], p["q_logstd.0.bias"])
         mean = mean.unsqueeze(1).expand(-1, self.K, -1)
         logvar = logvar.unsqueeze(1).expand(-1, self.K, -1)
         z = mean if eps is None else mean + eps * torch.exp(logvar / 2)

@@ -1,7 +1,8 @@
 """Layer-fused K-fold decoder of the regularised MNAR step (csrc/vpc_nmdec.hip; REG_notMIWAE_v2, src/models/VAE.py:2382-2471).
 
 CPU: the host-side index tables (every decoder / missingness parameter has exactly one place in the weight image and one in
-a partial block; the encoder's are skipped) and the oracle's model of the kernel's rounding points.
+a partial block of the decoder kernel; every encoder parameter one in a block of the encoder-backward kernel) and the
+oracle's model of the kernels' rounding points.
 GPU: NMTrainer(precision="bf16") - which runs the fused kernel at obs_dim 128 - against the float64 port of the oracle with
 the SAME operand rounding (loss <= 1e-5 rel, gradients <= 2e-3 of max: the Hardtanh gate, see tests/test_bf16_oracle.py),
 on full, ragged and multi-tile batches, other K / latent sizes, and against the GEMM chain it replaces."""
@@ -41,7 +42,7 @@ def test_index_tables_cpu():
     nimg, npart, nblk = C.c_int(), C.c_long(), C.c_int()
     assert _lib.lib().vpc_nmdec_layout(128, 20, d, L, C.byref(nimg), C.byref(npart), C.byref(nblk)) == 0
     enc = slice(2 * d, 2 * d + n_enc)
-    assert (gidx[enc] == -1).all()  # the encoder's gradients come from the GEMM chain
+    assert (gidx[enc] == -1).all()  # the encoder's gradients come from the encoder-backward kernel's own blocks (below)
     own = np.r_[0:2 * d, 2 * d + n_enc:2 * d + n_enc + n_dec]
     g = gidx[own].astype(np.int64)
     assert (g >= 0).all()
@@ -61,6 +62,24 @@ def test_index_tables_cpu():
     assert _lib.lib().vpc_nmdec_applicable(128, 20, 14, 10) == 0
     assert _lib.lib().vpc_nmdec_applicable(128, 2, 128, 10) == 0
     assert _lib.lib().vpc_nmdec_applicable(128, 20, 128, 10) == 1
+
+
+def test_encoder_backward_index_table_cpu():
+    """vpc_nmenc_build_indices: every encoder parameter (and nothing else) has exactly one place in a partial block of the
+    encoder-backward kernel."""
+    from vpc_amd import _lib
+    for d, L in ((128, 10), (128, 1), (128, 15)):
+        _, _, n_enc, n_dec = _tables(d, L)
+        n = 2 * d + n_enc + n_dec
+        npart = C.c_long()
+        assert _lib.lib().vpc_nmenc_build_indices(d, L, HID, None, C.byref(npart), n) == 0
+        inv = np.empty(npart.value, np.int32)
+        assert _lib.lib().vpc_nmenc_build_indices(d, L, HID, inv.ctypes.data_as(_lib.P), C.byref(npart), n) == 0
+        ids = inv[inv >= 0]
+        assert len(ids) == n_enc and len(np.unique(ids)) == n_enc
+        assert ids.min() == 2 * d and ids.max() == 2 * d + n_enc - 1
+        assert _lib.lib().vpc_nmenc_build_indices(d, L, HID, inv.ctypes.data_as(_lib.P), C.byref(npart), n + 1) != 0
+    assert _lib.lib().vpc_nmenc_build_indices(64, 10, HID, None, C.byref(npart), 0) != 0
 
 
 def _problem(d, L, K, B, seed=5):
@@ -139,6 +158,55 @@ def test_fused_decoder_unregularised_class_vs_emulating_oracle(B, K, L):
     which enters the softmax weights and sends its own gradient to (mean | logvar) through the K-fold exchange."""
     tr = _trainer_vs_oracle(128, L, K, B, 0.0, reg=False)
     assert tr.use_nmdec
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,L", [(256, 10), (1, 10), (63, 10), (65, 1), (1000, 15), (256 * 64 + 37, 10)])
+def test_encoder_backward_kernel_vs_torch(R, L):
+    """vpc_nmenc_bwd alone (ragged tiles, one row, several tiles per workgroup) against float64 torch with the kernel's rounding
+    points: bf16 dY / X / W operands, ELU' from the fp32 activations vpc_nmenc_fwd stored, bias gradients from the bf16 dY."""
+    from vpc_amd import notmiwae as nm
+    from vpc_amd.ops import step_pack_weights_bf16
+    d, K = 128, 20
+    model = nm.REG_notMIWAE_v2(d, 128, 10, L, {"batch_size": 8, "patience": 1}, K, 1).cuda()
+    tr = nm.NMTrainer(model, precision="bf16")
+    tr._ws(max(R // 2, 8))
+    assert tr.use_nmdec
+    pidx, _, _, einv = tr._nd_tables
+    g = torch.Generator().manual_seed(R + L)
+    xin = (torch.rand(R, d, generator=g) * (torch.rand(R, d, generator=g) < 0.6)).cuda()
+    dht = (torch.randn(R, 2 * L, generator=g) / R).cuda()
+    h1, h2, heads = (torch.empty(R, n, device="cuda") for n in (HID, HID, 2 * L))
+    step_pack_weights_bf16(model._flat, pidx, tr.nd_img)
+    nm.nmenc_fwd(tr.nd_img, xin, h1, h2, heads, R, d, L)
+    npart = int(einv.numel())
+    part = torch.empty(min((R + 63) // 64, 256) * npart, device="cuda")
+    grad = torch.full_like(tr.grad, 7.0)
+    nm.nmenc_bwd(tr.nd_img, xin, h1, h2, dht, part, einv, grad, R, d, L)
+    torch.cuda.synchronize()
+    v = {k: t.detach().double().cpu() for k, t in model._views().items()}
+    dy, X, H1, H2 = _bf(dht.cpu()), _bf(xin.cpu()), h1.double().cpu(), h2.double().cpu()
+    gate = lambda h: torch.where(h > 0, torch.ones_like(h), h + 1)
+    ref = {"Wh": dy.T @ _bf(H2), "bh": dy.sum(0)}
+    dh2 = _bf((dy @ _bf(v["Wh"])) * gate(H2))
+    ref["We2"], ref["be2"] = dh2.T @ _bf(H1), dh2.sum(0)
+    dh1 = _bf((dh2 @ _bf(v["We2"])) * gate(H1))
+    ref["We1"], ref["be1"] = dh1.T @ X, dh1.sum(0)
+    views = tr.g
+    # the trainer's gradient views alias tr.grad; read the same slices of the scratch gradient buffer
+    for k, r in ref.items():
+        off = views[k].data_ptr() - tr.grad.data_ptr()
+        got = grad.view(-1)[off // 4: off // 4 + r.numel()].double().cpu().reshape(r.shape)
+        # (dh2 / dh1 are rounded to bf16 from an fp32 sum here and a float64 one there: a few elements in 1e6 land on the other
+        # side of a rounding boundary - one bf16 ulp of one row's term; seen: 2.3e-5 of the largest entry at 16421 rows)
+        assert rel(got.numpy(), r.numpy()) < 1e-4, (k, rel(got.numpy(), r.numpy()))
+    # nothing outside the encoder segment is written
+    n_enc = HID * d + HID + HID * HID + HID + 2 * L * HID + 2 * L
+    assert (grad[:2 * d] == 7.0).all() and (grad[2 * d + n_enc:] == 7.0).all()
 
 
 @pytest.mark.gpu

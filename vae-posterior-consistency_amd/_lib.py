@@ -95,6 +95,8 @@ _PROTOS = {
     "vpc_nmdec_layout": [L_, I, I, I, IP, C.POINTER(C.c_long), IP],
     "vpc_nmdec_build_indices": [I, I, I, P, P, I],
     "vpc_nmenc_fwd": [P, P, P, P, P, L_, I, I, P],
+    "vpc_nmenc_bwd": [P, P, P, P, P, P, L_, P, P, L_, I, I, P],
+    "vpc_nmenc_build_indices": [I, I, I, P, C.POINTER(C.c_long), I],
     "vpc_nmdec_step": [P, P, P, P, P, L_, P, P, P, P, P, P, P, I, P, P, P, P, C.c_longlong, L_, L_, I, I, I, C.c_double, P],
     # PNP / EDDI encoder front-end
     "vpc_eddi_fold": [P, P, P, P, P, I, I, P],

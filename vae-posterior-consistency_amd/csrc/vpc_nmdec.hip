@@ -207,18 +207,19 @@ __device__ __forceinline__ void nd_heads(const float* W, const Op (&in)[4], int 
     }
 }
 // staging: a packed operand (tiles 2 kb, 2 kb + 1 of the lane's row) into slots slot0 + 2 kb (+ 1)
-template <bool BOTH = true>
+template <bool BOTH = true, int FT = ND_FT>
 __device__ __forceinline__ void nd_st_op(float* st, int row, int slot0, int kb, int q, Op op) {
     const u32x4 h = __builtin_bit_cast(u32x4, op);
-    const int o0 = bf_stage_off<ND_FT>(row, slot0 + 2 * kb, q);
+    const int o0 = bf_stage_off<FT>(row, slot0 + 2 * kb, q);
     *reinterpret_cast<u32x2*>(st + o0) = u32x2{h[0], h[1]};
     if (BOTH) *reinterpret_cast<u32x2*>(st + o0 + 64) = u32x2{h[2], h[3]};
 }
+template <int FT = ND_FT>
 __device__ __forceinline__ Op nd_st_frag(const float* st, int slot, int kb, int lane) {
     const int g = lane >> 4, rr = (lane >> 2) & 3, pp = lane & 3;
-    const int off = bf_stage_off<ND_FT>(32 * kb + 4 * g + rr, slot, pp);
+    const int off = bf_stage_off<FT>(32 * kb + 4 * g + rr, slot, pp);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * ND_FT);
+    const s16x4 h0 = ds_tr16(st + off), h1 = ds_tr16(st + off + 128 * FT);
     const s16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     return __builtin_bit_cast(Op, h);
 }
@@ -906,6 +907,195 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_fwd_kernel(NmeArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ encoder backward
+// The encoder's backward of the same step (autograd of VAE.py:2378-2384) as ONE launch + the reduction of its partial blocks, instead
+// of 3 wgrad + 2 dgrad GEMMs + a reduction: dht [R][2 L] -> dWh, dbh -> dh2 = ELU'(h2) (Wh^T dht) -> dW2, db2 -> dh1 -> dW1, db1.
+// 64-row tiles (4 waves x 16 rows), the images of W2 and Wh in LDS for the two dgrads (40 KB; W1 is not needed: no gradient goes to
+// x), 16 staging slots for the three wgrad rounds (32 KB).  148 accumulators per lane: dW1, dW2 64 each
+// (wave w: out tiles 2 w, 2 w + 1), dWh 16 (in tiles 2 w, 2 w + 1 of both out tiles), one selector-column tile for the biases.
+// ELU' comes from the fp32 h1 / h2 the forward stored - as the GEMM dgrads take it -, the bias gradients from the staged bf16 dY.
+constexpr int NE_FT = 16, NE_ST_DW = (ND_ROWS / 8) * NE_FT * 64;
+constexpr int NEB_LDS = (ND_HID * 64 + 32 * 64 + NE_ST_DW) * 4;  // W2, Wh, staging
+constexpr int NEB_REGS = 148, NEB_PART = NEB_REGS * ND_THREADS;
+constexpr int RE_1 = 0, RE_2 = 64, RE_H = 128, RE_B = 144;
+constexpr int NBE_B1 = 0, NBE_B2 = 2, NBE_BH = 4;  // columns of the bias tile: b1 / b2 of the wave's two tiles; bh tile w (waves 0, 1)
+struct NmebArgs {
+    const float* img;   // encoder part of the image buffer
+    const float* xin; const float* h1; const float* h2; const float* dht;
+    float* part;        // [blocks][NEB_PART]
+    long R; int L;
+};
+__device__ __forceinline__ f32x4 elu_gate_f32(f32x4 dy, f32x4 h) {  // dy * ELU'(pre) from the fp32 output h = ELU(pre)
+    return f32x4{h[0] > 0.f ? dy[0] : dy[0] * (h[0] + 1.f), h[1] > 0.f ? dy[1] : dy[1] * (h[1] + 1.f),
+                 h[2] > 0.f ? dy[2] : dy[2] * (h[2] + 1.f), h[3] > 0.f ? dy[3] : dy[3] * (h[3] + 1.f)};
+}
+__global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W2 = lds;
+    float* Wh = lds + ND_HID * 64;
+    float* st = Wh + 32 * 64;
+    {   // W2 and Wh of the encoder image (W1 is skipped)
+        const float* src = a.img + NeImg::oW2;
+        for (int i = threadIdx.x * 4; i < (ND_HID + 32) * 64; i += ND_THREADS * 4)
+            *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(src + i);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, q = lane >> 4;
+    f32x4 acc1[2][8], acc2[2][8], acch[2][2], accb = zero4();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        acch[i][0] = acch[i][1] = zero4();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc1[i][j] = acc2[i][j] = zero4();
+    }
+    auto sel_col = [&](int n, int cc) {
+        const uint32_t v = cc == n ? 0x3F803F80u : 0u;
+        return __builtin_bit_cast(Op, u32x4{v, v, v, v});
+    };
+    const long ntiles = (a.R + ND_ROWS - 1) / ND_ROWS;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int cc = c, qq = q;
+        launder(cc, qq);
+        const int r = 16 * w + cc, fl = 16 * qq + cc;
+        const long row = tile * ND_ROWS + r;
+        const bool ok = row < a.R;
+        const long rc = ok ? row : a.R - 1;
+        // ---- the lane's rows of dht (as one operand of 2 tiles), h2 (fp32 for ELU', packed for the wgrad)
+        f32x4 d0 = zero4(), d1 = zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o0 = 4 * qq + j, o1 = 16 + 4 * qq + j;
+            if (ok && o0 < 2 * a.L) d0[j] = a.dht[row * (2 * a.L) + o0];
+            if (ok && o1 < 2 * a.L) d1[j] = a.dht[row * (2 * a.L) + o1];
+        }
+        const Op dhb[1] = {nd_pack2(d0, d1)};
+        f32x4 hf[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.h2 + rc * 128 + 16 * t + 4 * qq);
+        ND_BARRIER();  // (the previous tile's last round is read)
+        // ---- Rh: dWh = dht^T h2, dbh   [dht 0-1 | h2 8-15]
+        nd_st_op<true, NE_FT>(st, r, 0, 0, qq, dhb[0]);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+        ND_BARRIER();
+#pragma unroll
+        for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+            const Op fa0 = nd_st_frag<NE_FT>(st, 0, kb, fl), fa1 = nd_st_frag<NE_FT>(st, 1, kb, fl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Op fb = nd_st_frag<NE_FT>(st, 8 + 2 * w + i, kb, fl);
+                acch[i][0] = VPC_MFMA_BF(fa0, fb, acch[i][0]);
+                acch[i][1] = VPC_MFMA_BF(fa1, fb, acch[i][1]);
+            }
+            if (w < 2) accb = VPC_MFMA_BF(w == 0 ? fa0 : fa1, sel_col(NBE_BH, cc), accb);
+        }
+        // ---- dh2 = ELU'(h2) (Wh^T dht)
+        Op dh2b[4];
+        nd_layer_T<128, 1, ND_HT>(Wh, dhb, fl, [&](int mt, f32x4 a0, f32x4 a1) {
+            dh2b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf[mt]), elu_gate_f32(a1, hf[mt + 1]));
+        });
+        launder(cc, qq);
+        // h1 of the lane's row
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.h1 + rc * 128 + 16 * t + 4 * qq);
+        ND_BARRIER();  // (Rh is read)
+        // ---- R2: dW2 = dh2^T h1, db2   [dh2 0-7 | h1 8-15]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            nd_st_op<true, NE_FT>(st, r, 0, kb, qq, dh2b[kb]);
+            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+        }
+        ND_BARRIER();
+#pragma unroll
+        for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+            Op fb[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) fb[nt] = nd_st_frag<NE_FT>(st, 8 + nt, kb, fl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Op fa = nd_st_frag<NE_FT>(st, 2 * w + i, kb, fl);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) acc2[i][nt] = VPC_MFMA_BF(fa, fb[nt], acc2[i][nt]);
+                accb = VPC_MFMA_BF(fa, sel_col(NBE_B2 + i, cc), accb);
+            }
+        }
+        // ---- dh1 = ELU'(h1) (W2^T dh2)
+        Op dh1b[4];
+        nd_layer_T<128, 4, ND_HT>(W2, dh2b, fl, [&](int mt, f32x4 a0, f32x4 a1) {
+            dh1b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf[mt]), elu_gate_f32(a1, hf[mt + 1]));
+        });
+        launder(cc, qq);
+        // the encoder input of the lane's row
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.xin + rc * 128 + 16 * t + 4 * qq);
+        ND_BARRIER();  // (R2 is read)
+        // ---- R1: dW1 = dh1^T x, db1   [dh1 0-7 | x * mask 8-15]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            nd_st_op<true, NE_FT>(st, r, 0, kb, qq, dh1b[kb]);
+            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+        }
+        ND_BARRIER();
+#pragma unroll
+        for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
+            Op fb[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) fb[nt] = nd_st_frag<NE_FT>(st, 8 + nt, kb, fl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Op fa = nd_st_frag<NE_FT>(st, 2 * w + i, kb, fl);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) acc1[i][nt] = VPC_MFMA_BF(fa, fb[nt], acc1[i][nt]);
+                accb = VPC_MFMA_BF(fa, sel_col(NBE_B1 + i, cc), accb);
+            }
+        }
+    }
+    float* part = a.part + (long)blockIdx.x * NEB_PART + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[(RE_1 + (8 * i + nt) * 4 + j) * ND_THREADS] = acc1[i][nt][j];
+                part[(RE_2 + (8 * i + nt) * 4 + j) * ND_THREADS] = acc2[i][nt][j];
+            }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(RE_H + (2 * i + m2) * 4 + j) * ND_THREADS] = acch[i][m2][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(RE_B + j) * ND_THREADS] = accb[j];
+}
+
+// fixed-order reduction of the encoder's partial blocks, read in layout order as the decoder's (nmdec_finalize_kernel below):
+// 8 positions of 4 floats x 32 block groups per workgroup; grad[inv_idx[position]] = sum over blocks
+__global__ __launch_bounds__(256) void nmenc_reduce_kernel(const float* part, int n_blocks, const int* inv_idx, float* grad) {
+    __shared__ f32x4 sh[32][8];
+    const int blk = blockIdx.x, pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
+    const int p4 = blk * 8 + pi;
+    f32x4 s0 = zero4();
+    if (p4 < NEB_PART / 4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part) + p4;
+#pragma unroll 4
+        for (int b = bg; b < n_blocks; b += 32) s0 += p[(long)b * (NEB_PART / 4)];
+    }
+    sh[bg][pi] = s0;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int pos = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (blk * 8 + pos < NEB_PART / 4) {
+            float t = sh[0][pos][k];
+#pragma unroll
+            for (int g = 1; g < 32; ++g) t += sh[g][pos][k];
+            const int id = inv_idx[4 * (blk * 8 + pos) + k];
+            if (id >= 0) grad[id] = t;
+        }
+    }
+}
+
 // fixed-order reduction of the partial blocks into the flat gradient (W | b of the missingness model and the decoder segment)
 // + the loss terms (block 0), as nm_finalize_kernel of vpc_nm.hip
 struct NmdFinArgs {
@@ -1151,6 +1341,63 @@ int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, floa
     if (!lds_attr_done(reinterpret_cast<const void*>(nmenc_fwd_kernel), NE_LDS)) return VPC_ERR_HIP;
     hipLaunchKernelGGL(nmenc_fwd_kernel, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(ND_THREADS), NE_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// Encoder backward of the stacked passes (autograd of VAE.py:2378-2384 behind d loss / d heads) in one launch + the fixed-order
+// reduction of its partial blocks: dht [R][2 L], h1 / h2 [R][128] (fp32, as vpc_nmenc_fwd stored them), xin [R][128] -> the
+// gradients of We1 be1 We2 be2 [Wmu ; Wls] [bmu ; bls] inside grad (the model's flat gradient buffer), at the positions
+// inv_idx names (vpc_nmenc_build_indices).  part: scratch of part_floats floats (the decoder's partial blocks, already reduced,
+// serve: vpc_nmdec_layout's max_blocks x part_floats is always enough for one block per 64-row tile or one per CU).
+int vpc_nmenc_bwd(const float* img, const float* xin, const float* h1, const float* h2, const float* dht, float* part,
+                  long part_floats, const int* inv_idx, float* grad, long R, int d, int L, void* stream) {
+    if (!img || !xin || !h1 || !h2 || !dht || !part || !inv_idx || !grad || R <= 0) return VPC_ERR_ARG;
+    if (!nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(xin) | reinterpret_cast<uintptr_t>(h1) |
+         reinterpret_cast<uintptr_t>(h2) | reinterpret_cast<uintptr_t>(part)) & 15)
+        return VPC_ERR_ARG;
+    const long tiles = (R + ND_ROWS - 1) / ND_ROWS;
+    long blocks = num_cus();  // (290 registers per lane: one workgroup per CU)
+    if (tiles < blocks) blocks = tiles;
+    if (part_floats / NEB_PART < blocks) blocks = part_floats / NEB_PART;
+    if (blocks < 1) return VPC_ERR_ARG;
+    NmebArgs a{img + NdImg::total, xin, h1, h2, dht, part, R, L};
+    hipStream_t st = (hipStream_t)stream;
+    if (!lds_attr_done(reinterpret_cast<const void*>(nmenc_bwd_kernel), NEB_LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(nmenc_bwd_kernel, dim3((unsigned)blocks), dim3(ND_THREADS), NEB_LDS, st, a);
+    if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(nmenc_reduce_kernel, dim3((NEB_PART / 4 + 7) / 8), dim3(256), 0, st, part, (int)blocks, inv_idx, grad);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// inv_idx [*part_floats] for vpc_nmenc_bwd: the flat parameter index (layout of vpc_nmdec_build_indices, n entries) whose gradient a
+// position of an encoder partial block holds, -1 where none.  inv_idx == NULL: only *part_floats is written.
+int vpc_nmenc_build_indices(int d, int L, int hid, int* inv_idx, long* part_floats, int n) {
+    if (hid != ND_HID || !nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
+    if (part_floats) *part_floats = NEB_PART;
+    if (!inv_idx) return VPC_OK;
+    const int n_enc = hid * d + hid + hid * hid + hid + 2 * L * hid + 2 * L;
+    const int n_dec = hid * L + hid + hid * hid + hid + 2 * d * hid + 2 * d;
+    if (n != 2 * d + n_enc + n_dec) return VPC_ERR_ARG;
+    for (int i = 0; i < NEB_PART; ++i) inv_idx[i] = -1;
+    auto pos = [](int reg, int w, int q, int c) { return reg * ND_THREADS + 64 * w + 16 * q + c; };
+    const int e0 = 2 * d, oWe1 = e0, obe1 = oWe1 + hid * d, oWe2 = obe1 + hid, obe2 = oWe2 + hid * hid, oWh = obe2 + hid,
+              obh = oWh + 2 * L * hid;
+    for (int r = 0; r < hid; ++r) {  // out feature r of the two hidden layers: tile mt = r >> 4 owned by wave mt >> 1
+        const int mt = r >> 4, w = mt >> 1, i = mt & 1, q = (r >> 2) & 3, j = r & 3;
+        for (int f = 0; f < d; ++f) inv_idx[pos(RE_1 + (8 * i + (f >> 4)) * 4 + j, w, q, f & 15)] = oWe1 + r * d + f;
+        inv_idx[pos(RE_B + j, w, q, NBE_B1 + i)] = obe1 + r;
+        for (int f = 0; f < hid; ++f) inv_idx[pos(RE_2 + (8 * i + (f >> 4)) * 4 + j, w, q, f & 15)] = oWe2 + r * hid + f;
+        inv_idx[pos(RE_B + j, w, q, NBE_B2 + i)] = obe2 + r;
+    }
+    for (int r = 0; r < 2 * L; ++r) {  // head rows: out tile m2 = r >> 4; in feature f: tile f >> 4 owned by wave (f >> 4) >> 1
+        const int m2 = r >> 4, q = (r >> 2) & 3, j = r & 3;
+        for (int f = 0; f < hid; ++f) {
+            const int ft = f >> 4, w = ft >> 1, i = ft & 1;
+            inv_idx[pos(RE_H + (2 * i + m2) * 4 + j, w, q, f & 15)] = oWh + r * hid + f;
+        }
+        inv_idx[pos(RE_B + j, m2, q, NBE_BH)] = obh + r;
+    }
+    return VPC_OK;
 }
 
 }  // extern "C"

@@ -130,11 +130,21 @@ def nmdec_tables(model, device):
     inv = np.full(npart.value, -1, np.int32)
     own = np.nonzero(gidx >= 0)[0]
     inv[gidx[own]] = own.astype(np.int32)
-    return torch.from_numpy(pidx).to(device), torch.from_numpy(gidx).to(device), torch.from_numpy(inv).to(device)
+    # the same for the encoder-backward kernel's partial blocks
+    nparte = C.c_long()
+    check(lib().vpc_nmenc_build_indices(d, Ld, HID, None, C.byref(nparte), n), "vpc_nmenc_build_indices")
+    inve = np.empty(nparte.value, np.int32)
+    check(lib().vpc_nmenc_build_indices(d, Ld, HID, inve.ctypes.data_as(L.P), C.byref(nparte), n), "vpc_nmenc_build_indices")
+    return tuple(torch.from_numpy(a).to(device) for a in (pidx, gidx, inv, inve))
 
 
 def nmenc_fwd(img, xin, h1, h2, heads, R, d, Ld):
     check(lib().vpc_nmenc_fwd(ptr(img), ptr(xin), ptr(h1), ptr(h2), ptr(heads), R, d, Ld, stream_ptr()), "vpc_nmenc_fwd")
+
+
+def nmenc_bwd(img, xin, h1, h2, dht, part, inv, grad, R, d, Ld):
+    check(lib().vpc_nmenc_bwd(ptr(img), ptr(xin), ptr(h1), ptr(h2), ptr(dht), ptr(part), part.numel(), ptr(inv), ptr(grad),
+                              R, d, Ld, stream_ptr()), "vpc_nmenc_bwd")
 
 
 def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, inv, grad, out8, loss_f32, accum, B, B_global, K, d,
@@ -620,10 +630,11 @@ class NMTrainer:
         self.z, self.g1, self.g2, self.Y = e(Mg, Ld), e(Mg, HID), e(Mg, HID), e(Mg, 2 * d)
         self.G, self.gheads, self.dht = e(Mg, 2 * d), e(R, 2 * Ld), e(R, 2 * Ld)
         self.dg2, self.dg1, self.dz = e(Mg, HID), e(Mg, HID), e(Mg, Ld)
-        self.dh2, self.dh1 = e(R, HID), e(R, HID)
+        Rg = 0 if self.use_nmdec else R     # (the fused path's encoder backward is one kernel too: nmenc_bwd)
+        self.dh2, self.dh1 = e(Rg, HID), e(Rg, HID)
         # per-layer partial buffers of the six weight gradients (summed by ONE launch at the end of the backward pass)
         self.wg_shapes = [(M, 2 * d, HID), (M, HID, HID), (M, HID, Ld), (R, 2 * Ld, HID), (R, HID, HID), (R, HID, d)]
-        sizes = [0 if (self.use_nmdec and i < 3) else int(lib().vpc_linear_wgrad_scratch(*sh))
+        sizes = [0 if self.use_nmdec else int(lib().vpc_linear_wgrad_scratch(*sh))
                  for i, sh in enumerate(self.wg_shapes)]
         buf = e(sum(sizes))
         self._wg_cache = {}
@@ -729,19 +740,30 @@ class NMTrainer:
         if self.use_nmdec:
             # K-fold rsample, decoder, loss, decoder backward and the K-fold sum of dz in ONE kernel (csrc/vpc_nmdec.hip): the
             # decoder / missingness-model gradients land in self.grad, d loss / d heads in self.dht
-            pidx, gidx, ginv = self._nd_tables
+            pidx, gidx, ginv, einv = self._nd_tables
             t("dec_fused", nmdec_step, self.nd_img, xf, mf, mp, self.heads, self.eps, self.dht, self.nd_part, self.nd_stat,
               gidx, ginv, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
               _state, rng_inc)
+            # the encoder's backward in one kernel + its reduction (nmenc_bwd_kernel), through the decoder's partial-block buffer
+            t("enc_bwd", nmenc_bwd, self.nd_img, self.xin, self.h1, self.h2, self.dht, self.nd_part, einv, self.grad, R, d, Ld)
         else:
             self._step_decoder_gemms(xf, mf, mp, B, Bg, alpha, _state, rng_inc, t, v, wgrad)
+            self._step_encoder_bwd_gemms(R, t, v, wgrad)
+        if pend:
+            wgrad_reduce(pend, self._wg_cache)  # (buffers and gradient views are fixed for a batch size: arrays built once)
+        self._step_tail(t, _state)
+
+    def _step_encoder_bwd_gemms(self, R, t, v, wgrad):
+        m, g = self.model, self.g
+        d, Ld = m.obs_dim, m.latent_dim
         wgrad("enc_bwd", 3, self.dht, self.h2, g["Wh"], g["bh"])
         t("enc_bwd", linear_dgrad, self.dht, v["Wh"], self.dh2, R, 2 * Ld, HID, x_out=self.h2, act_prev=ACT_ELU, precision=self.prec)
         wgrad("enc_bwd", 4, self.dh2, self.h1, g["We2"], g["be2"])
         t("enc_bwd", linear_dgrad, self.dh2, v["We2"], self.dh1, R, HID, HID, x_out=self.h1, act_prev=ACT_ELU, precision=self.prec)
         wgrad("enc_bwd", 5, self.dh1, self.xin, g["We1"], g["be1"])
-        if pend:
-            wgrad_reduce(pend, self._wg_cache)  # (buffers and gradient views are fixed for a batch size: arrays built once)
+
+    def _step_tail(self, t, _state):
+        m = self.model
         if self.world_size > 1:  # ONE collective per step: RCCL on the compute stream, or torch.distributed (dist.py)
             from . import dist as dp_mod
             if not getattr(self, "_coll_ready", False):
