@@ -934,13 +934,36 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
     float* W2 = lds;
     float* Wh = lds + ND_HID * 64;
     float* st = Wh + 32 * 64;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, q = lane >> 4;
+    const long ntiles = (a.R + ND_ROWS - 1) / ND_ROWS;
+    // the lane's row of a tile: dht (two tiles of 16 head outputs), h2, h1, x * mask (fp32, features 16 t + 4 q + j).  Every array
+    // is requested for the NEXT tile right behind its last use in this one, so its latency hides under the rest of the tile
+    // (one wave per SIMD has nothing else to hide it with); the first tile's requests fly under the image load.
+    f32x4 d0, d1, hf2[8], hf1[8], hfx[8];
+    auto req_d = [&](long tile) {
+        const long row = tile * ND_ROWS + 16 * w + c;
+        const bool ok = row < a.R;
+        d0 = d1 = zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o0 = 4 * q + j, o1 = 16 + 4 * q + j;
+            if (ok && o0 < 2 * a.L) d0[j] = a.dht[row * (2 * a.L) + o0];
+            if (ok && o1 < 2 * a.L) d1[j] = a.dht[row * (2 * a.L) + o1];
+        }
+    };
+    auto req = [&](f32x4 (&h)[8], const float* src, long tile) {
+        const long row = tile * ND_ROWS + 16 * w + c;
+        const long rc = row < a.R ? row : a.R - 1;  // (rows past the end: dht is 0 there, whatever h holds)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) h[t] = *reinterpret_cast<const f32x4*>(src + rc * 128 + 16 * t + 4 * q);
+    };
+    if ((long)blockIdx.x < ntiles) { req_d(blockIdx.x); req(hf2, a.h2, blockIdx.x); req(hf1, a.h1, blockIdx.x); req(hfx, a.xin, blockIdx.x); }
     {   // W2 and Wh of the encoder image (W1 is skipped)
         const float* src = a.img + NeImg::oW2;
         for (int i = threadIdx.x * 4; i < (ND_HID + 32) * 64; i += ND_THREADS * 4)
             *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(src + i);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, q = lane >> 4;
     f32x4 acc1[2][8], acc2[2][8], acch[2][2], accb = zero4();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -952,31 +975,17 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         const uint32_t v = cc == n ? 0x3F803F80u : 0u;
         return __builtin_bit_cast(Op, u32x4{v, v, v, v});
     };
-    const long ntiles = (a.R + ND_ROWS - 1) / ND_ROWS;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int cc = c, qq = q;
         launder(cc, qq);
         const int r = 16 * w + cc, fl = 16 * qq + cc;
-        const long row = tile * ND_ROWS + r;
-        const bool ok = row < a.R;
-        const long rc = ok ? row : a.R - 1;
-        // ---- the lane's rows of dht (as one operand of 2 tiles), h2 (fp32 for ELU', packed for the wgrad)
-        f32x4 d0 = zero4(), d1 = zero4();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o0 = 4 * qq + j, o1 = 16 + 4 * qq + j;
-            if (ok && o0 < 2 * a.L) d0[j] = a.dht[row * (2 * a.L) + o0];
-            if (ok && o1 < 2 * a.L) d1[j] = a.dht[row * (2 * a.L) + o1];
-        }
+        const long nxt = tile + gridDim.x;
         const Op dhb[1] = {nd_pack2(d0, d1)};
-        f32x4 hf[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.h2 + rc * 128 + 16 * t + 4 * qq);
         ND_BARRIER();  // (the previous tile's last round is read)
         // ---- Rh: dWh = dht^T h2, dbh   [dht 0-1 | h2 8-15]
         nd_st_op<true, NE_FT>(st, r, 0, 0, qq, dhb[0]);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+        for (int kb = 0; kb < 4; ++kb) nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf2[2 * kb], hf2[2 * kb + 1]));
         ND_BARRIER();
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
@@ -992,18 +1001,16 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         // ---- dh2 = ELU'(h2) (Wh^T dht)
         Op dh2b[4];
         nd_layer_T<128, 1, ND_HT>(Wh, dhb, fl, [&](int mt, f32x4 a0, f32x4 a1) {
-            dh2b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf[mt]), elu_gate_f32(a1, hf[mt + 1]));
+            dh2b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf2[mt]), elu_gate_f32(a1, hf2[mt + 1]));
         });
         launder(cc, qq);
-        // h1 of the lane's row
-#pragma unroll
-        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.h1 + rc * 128 + 16 * t + 4 * qq);
+        if (nxt < ntiles) { req_d(nxt); req(hf2, a.h2, nxt); }
         ND_BARRIER();  // (Rh is read)
         // ---- R2: dW2 = dh2^T h1, db2   [dh2 0-7 | h1 8-15]
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             nd_st_op<true, NE_FT>(st, r, 0, kb, qq, dh2b[kb]);
-            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf1[2 * kb], hf1[2 * kb + 1]));
         }
         ND_BARRIER();
 #pragma unroll
@@ -1022,19 +1029,18 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         // ---- dh1 = ELU'(h1) (W2^T dh2)
         Op dh1b[4];
         nd_layer_T<128, 4, ND_HT>(W2, dh2b, fl, [&](int mt, f32x4 a0, f32x4 a1) {
-            dh1b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf[mt]), elu_gate_f32(a1, hf[mt + 1]));
+            dh1b[mt >> 1] = nd_pack2(elu_gate_f32(a0, hf1[mt]), elu_gate_f32(a1, hf1[mt + 1]));
         });
         launder(cc, qq);
-        // the encoder input of the lane's row
-#pragma unroll
-        for (int t = 0; t < 8; ++t) hf[t] = *reinterpret_cast<const f32x4*>(a.xin + rc * 128 + 16 * t + 4 * qq);
+        if (nxt < ntiles) req(hf1, a.h1, nxt);
         ND_BARRIER();  // (R2 is read)
         // ---- R1: dW1 = dh1^T x, db1   [dh1 0-7 | x * mask 8-15]
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             nd_st_op<true, NE_FT>(st, r, 0, kb, qq, dh1b[kb]);
-            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf[2 * kb], hf[2 * kb + 1]));
+            nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hfx[2 * kb], hfx[2 * kb + 1]));
         }
+        if (nxt < ntiles) req(hfx, a.xin, nxt);
         ND_BARRIER();
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
