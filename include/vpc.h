@@ -362,6 +362,18 @@ int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, floa
 int vpc_nmenc_bwd(const float* img, const float* xin, const float* h1, const float* h2, const float* dht, float* part,
                   long part_floats, const int* inv_idx, float* grad, long R, int d, int L, void* stream);
 int vpc_nmenc_build_indices(int d, int L, int hid, int* inv_idx, long* part_floats, int n);
+/* everything behind vpc_nmenc_fwd of a SINGLE-DEVICE step (train.py:87-101, 116: loss.backward(); optimizer.step()) in three launches:
+ * vpc_nmdec_step's tile kernel, vpc_nmenc_bwd's tile kernel and one tail launch that sums both sets of partial blocks into grad
+ * (fixed order), applies torch.optim.Adam (as vpc_adam_step, host step count) to every gradient it finishes, re-packs that
+ * parameter's place in the bf16 image (pack_idx of vpc_nmdec_build_indices; img is read by the tile kernels and updated by the tail)
+ * and writes the loss terms.  Arguments as those two calls; inv_idx (decoder blocks) is required; part_e: its own scratch of
+ * part_e_floats floats (max_blocks x vpc_nmenc_build_indices' part_floats suffices) - both sets are live until the tail. */
+int vpc_nm_fused_bwd_step(float* img, const float* x, const float* mask, const float* mask_p, const float* xin, const float* h1,
+                          const float* h2, const float* heads, long ldh, const float* eps, float* dht, float* part,
+                          double* stat_part, float* part_e, long part_e_floats, const int* inv_idx, const int* inv_idx_e,
+                          float* grad, int n, double* out8, float* loss_f32, float* accum, long B, long B_global, int K, int d,
+                          int L, double alpha, float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                          float beta2, float eps_adam, long step, const int* pack_idx, void* stream);
 int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
                    const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx,
                    float* grad, int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,

@@ -273,3 +273,41 @@ def test_graph_replay_equals_eager_fused():
         assert res[0][0] == other[0]
         assert torch.equal(res[0][1], other[1])
         assert res[0][2] == other[2]
+
+
+@pytest.mark.gpu
+def test_fused_tail_equals_separate_launches_and_follows_parameter_writes():
+    """The single-device eager step ends in ONE tail launch (both reductions + Adam + the image re-pack, vpc_nm_fused_bwd_step).
+    (a) It is bit-identical to the separate launches (per-launch timer mode: finalize, encoder reduction, vpc_adam_step, pack).
+    (b) A torch write to a parameter between steps is seen (version counters -> the image is re-packed), and invalidate_image()
+    covers writes torch does not count."""
+    from vpc_amd import notmiwae as nm
+    B, d, K, L = 96, 128, 20, 10
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(B, d, device="cuda", generator=g)
+    m = (torch.rand(B, d, device="cuda", generator=g) < 0.6).float()
+
+    def run(separate, poke):
+        torch.manual_seed(12)
+        model = nm.REG_notMIWAE_v2(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, lr=1e-3, seed=5, precision="bf16")
+        losses = []
+        for it in range(5):
+            if separate:
+                tr.timers = {}
+            if it == 2 and poke == "torch":
+                with torch.no_grad():
+                    model.seq_decoder[2].weight.mul_(0.5)
+            if it == 2 and poke == "data":
+                model.seq_decoder[2].weight.data.mul_(0.5)
+                tr.invalidate_image()
+            tr.step(x, m, alpha=0.5, p_missingness=50)
+            losses.append(tr.loss_value())
+        assert tr.use_nmdec
+        return losses, model._flat.clone()
+
+    for poke in (None, "torch", "data"):
+        a, b = run(False, poke), run(True, poke)
+        assert a[0] == b[0], (poke, a[0], b[0])
+        assert torch.equal(a[1], b[1]), poke
+    assert run(False, None)[0][2:] != run(False, "torch")[0][2:]

@@ -97,6 +97,8 @@ _PROTOS = {
     "vpc_nmenc_fwd": [P, P, P, P, P, L_, I, I, P],
     "vpc_nmenc_bwd": [P, P, P, P, P, P, L_, P, P, L_, I, I, P],
     "vpc_nmenc_build_indices": [I, I, I, P, C.POINTER(C.c_long), I],
+    "vpc_nm_fused_bwd_step": [P, P, P, P, P, P, P, P, L_, P, P, P, P, P, L_, P, P, P, I, P, P, P, L_, L_, I, I, I, C.c_double,
+                              P, P, P, F, F, F, F, L_, P, P],
     "vpc_nmdec_step": [P, P, P, P, P, L_, P, P, P, P, P, P, P, I, P, P, P, P, C.c_longlong, L_, L_, I, I, I, C.c_double, P],
     # PNP / EDDI encoder front-end
     "vpc_eddi_fold": [P, P, P, P, P, I, I, P],

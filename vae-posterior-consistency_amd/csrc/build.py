@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["vpc_enc.hip", "vpc_dec.hip", "vpc_dec8.hip", "vpc_step.hip", "vpc_small.hip", "vpc_misc.hip", "vpc_reward.hip", "vpc_gemm.hip", "vpc_nm.hip", "vpc_nmdec.hip", "vpc_eddi.hip", "vpc_rccl.hip"]
-HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h", "vpc_dec_args.h", "vpc_bf16.h", "vpc_rng.h", "../../include/vpc.h"]
+HDRS = ["vpc_device.h", "vpc_layout.h", "vpc_abi_internal.h", "vpc_dec_args.h", "vpc_bf16.h", "vpc_rng.h", "vpc_adam.h", "../../include/vpc.h"]
 LIB = os.path.join(HERE, "libvpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = os.environ.get("VPC_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-variable",

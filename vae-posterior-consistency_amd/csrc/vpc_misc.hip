@@ -5,6 +5,7 @@
 #include "vpc_device.h"
 #include "vpc_rng.h"
 #include "vpc_bf16.h"
+#include "vpc_adam.h"
 #include "vpc_abi_internal.h"
 #include <cmath>
 #include <cstdlib>
@@ -101,29 +102,6 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int* __re
 // out[i] = scale * sum_b part[b * stride + idx[i]].  A 256-thread block handles 32 parameters x 8 block
 // groups (thread (pi, bg) sums blocks bg, bg+8, ...), then the 8 group sums are added in a fixed order:
 // bitwise reproducible, and 8x more loads in flight than one thread per parameter.
-// optional optimiser update fused into the gradient reduction (Adam is elementwise: the thread that finishes
-// gradient i owns parameter i); param == nullptr disables it
-struct AdamFuse {
-    float* param; float* m; float* v; const int* pack_idx; float* img;
-    float lr, b1, b2, eps, bc1, bc2_sqrt;
-    int bf16c;  // 1: (pack_idx, img) are the compact bf16 image tables of the whole-step kernel (vpc_step_build_indices_bf16)
-};
-__device__ __forceinline__ void adam_apply(const AdamFuse& A, int i, float g) {
-#pragma clang fp contract(off)  // one rounding sequence wherever this is inlined (stand-alone Adam == fused Adam, bitwise)
-    const float mi = A.b1 * A.m[i] + (1.f - A.b1) * g;
-    const float vi = A.b2 * A.v[i] + (1.f - A.b2) * g * g;
-    A.m[i] = mi;
-    A.v[i] = vi;
-    const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
-    const float pnew = A.param[i] - (A.lr / A.bc1) * (mi / denom);
-    A.param[i] = pnew;
-    if (A.pack_idx) {
-        const int e = A.pack_idx[i];
-        if (!A.bf16c) A.img[e] = pnew;
-        else if (e < 0) A.img[-(e + 1)] = pnew;  // the layer-1 bias stays fp32
-        else reinterpret_cast<unsigned short*>(A.img)[e] = (unsigned short)(pk_bf16(pnew, 0.f) & 0xffffu);
-    }
-}
 __device__ __forceinline__ void reduce_body(const float* __restrict__ part, int nblocks, long stride,
                                             const int* __restrict__ idx, float* __restrict__ out, int n, float scale,
                                             int blk, float (*sh)[32], const AdamFuse* adam = nullptr, int base = 0) {

@@ -25,8 +25,10 @@
 #include "vpc_abi_internal.h"
 #include "vpc_device.h"
 #include "vpc_bf16.h"
+#include "vpc_adam.h"
 #include "vpc_dec_args.h"
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <type_traits>
 
@@ -1076,67 +1078,63 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
     for (int j = 0; j < 4; ++j) part[(RE_B + j) * ND_THREADS] = accb[j];
 }
 
-// fixed-order reduction of the encoder's partial blocks, read in layout order as the decoder's (nmdec_finalize_kernel below):
-// 8 positions of 4 floats x 32 block groups per workgroup; grad[inv_idx[position]] = sum over blocks
-__global__ __launch_bounds__(256) void nmenc_reduce_kernel(const float* part, int n_blocks, const int* inv_idx, float* grad) {
+// fixed-order reduction of partial blocks read in LAYOUT order (16 bytes per lane, a wave reads full 128-byte lines): a workgroup
+// takes 8 positions of 4 floats x 32 block groups; every thread has its loads in flight at once; summation order: blocks g, g + 32,
+// ... per group, then groups 0 .. 31 (fixed: reproducible).  sink(parameter index, sum) for the positions inv_idx names.
+template <typename F>
+__device__ __forceinline__ void layout_sum(const float* part, int part4, int n_blocks, const int* inv_idx, int blk, F&& sink) {
     __shared__ f32x4 sh[32][8];
-    const int blk = blockIdx.x, pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
+    const int pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
     const int p4 = blk * 8 + pi;
     f32x4 s0 = zero4();
-    if (p4 < NEB_PART / 4) {
+    if (p4 < part4) {
         const f32x4* p = reinterpret_cast<const f32x4*>(part) + p4;
 #pragma unroll 4
-        for (int b = bg; b < n_blocks; b += 32) s0 += p[(long)b * (NEB_PART / 4)];
+        for (int b = bg; b < n_blocks; b += 32) s0 += p[(long)b * part4];
     }
     sh[bg][pi] = s0;
     __syncthreads();
     if (threadIdx.x < 32) {
         const int pos = threadIdx.x >> 2, k = threadIdx.x & 3;
-        if (blk * 8 + pos < NEB_PART / 4) {
+        if (blk * 8 + pos < part4) {
             float t = sh[0][pos][k];
 #pragma unroll
             for (int g = 1; g < 32; ++g) t += sh[g][pos][k];
             const int id = inv_idx[4 * (blk * 8 + pos) + k];
-            if (id >= 0) grad[id] = t;
+            if (id >= 0) sink(id, t);
         }
     }
 }
+constexpr int ND_FIN_BLOCKS = (ND_PART / 4 + 7) / 8, NE_FIN_BLOCKS = (NEB_PART / 4 + 7) / 8;
+
+// the encoder's partial blocks alone (vpc_nmenc_bwd)
+__global__ __launch_bounds__(256) void nmenc_reduce_kernel(const float* part, int n_blocks, const int* inv_idx, float* grad) {
+    layout_sum(part, NEB_PART / 4, n_blocks, inv_idx, blockIdx.x, [&](int id, float t) { grad[id] = t; });
+}
 
 // fixed-order reduction of the partial blocks into the flat gradient (W | b of the missingness model and the decoder segment)
-// + the loss terms (block 0), as nm_finalize_kernel of vpc_nm.hip
+// + the loss terms (block 0), as nm_finalize_kernel of vpc_nm.hip.  With part_e: the encoder-backward kernel's blocks too (workgroups
+// behind the decoder's), and with adam.param: Adam on every finished gradient + the re-pack of its place in the bf16 image - the whole
+// tail of a single-device step in one launch (vpc_nm_fused_bwd_step).
 struct NmdFinArgs {
     const float* part; const double* stat_part; int n_blocks;
     const int* grad_idx; float* grad; int n;   // grad[i] = sum over blocks of part[block][grad_idx[i]] where grad_idx[i] >= 0
     const int* inv_idx;                        // optional [ND_PART]: parameter of a block position (-1: none) - the blocks are then
-                                               // read in layout order, 16 bytes per lane (reduce_body_v2 of vpc_misc.hip)
+                                               // read in layout order (layout_sum)
     int B, K, L, reg; double alpha, inv_B;
     double* out; float* loss_f32; float* accum; long long* state; long long rng_inc;
+    const float* part_e; int n_blocks_e; const int* inv_idx_e;
+    AdamFuse adam;
 };
 __global__ __launch_bounds__(256) void nmdec_finalize_kernel(NmdFinArgs a) {
     if (blockIdx.x > 0 && a.inv_idx) {
-        // 8 positions of 4 floats x 32 block groups per workgroup: every thread has its loads in flight at once, a wave reads full
-        // 128-byte lines; summation order: blocks g, g + 32, ... per group, then groups 0 .. 31 (fixed: reproducible)
-        __shared__ f32x4 sh[32][8];
-        const int blk = blockIdx.x - 1, pi = threadIdx.x & 7, bg = threadIdx.x >> 3;
-        const int p4 = blk * 8 + pi;
-        f32x4 s0 = zero4();
-        if (p4 < ND_PART / 4) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.part) + p4;
-#pragma unroll 4
-            for (int b = bg; b < a.n_blocks; b += 32) s0 += p[(long)b * (ND_PART / 4)];
-        }
-        sh[bg][pi] = s0;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            const int pos = threadIdx.x >> 2, k = threadIdx.x & 3;
-            if (blk * 8 + pos < ND_PART / 4) {
-                float t = sh[0][pos][k];
-#pragma unroll
-                for (int g = 1; g < 32; ++g) t += sh[g][pos][k];
-                const int id = a.inv_idx[4 * (blk * 8 + pos) + k];
-                if (id >= 0) a.grad[id] = t;
-            }
-        }
+        const int blk = blockIdx.x - 1;
+        auto sink = [&](int id, float t) {
+            a.grad[id] = t;
+            if (a.adam.param) adam_apply(a.adam, id, t);
+        };
+        if (blk < ND_FIN_BLOCKS) layout_sum(a.part, ND_PART / 4, a.n_blocks, a.inv_idx, blk, sink);
+        else layout_sum(a.part_e, NEB_PART / 4, a.n_blocks_e, a.inv_idx_e, blk - ND_FIN_BLOCKS, sink);
         return;
     }
     if (blockIdx.x > 0) {
@@ -1282,16 +1280,11 @@ int vpc_nmdec_build_indices(int d, int L, int hid, int* pack_idx, int* grad_idx,
     return VPC_OK;
 }
 
-// The fused decoder + loss + decoder backward of one regularised MNAR step (two launches: the tile kernel and the fixed-order
-// reduction of its partial blocks).  heads [2 B][ldh] = the encoder's (mean | logvar) rows of the q pass, then of the p pass;
-// eps [2 B K][L]; dht [2 B][2 L] receives the gradient w.r.t. heads (K-fold sum of dz + the analytic KL gradients);
-// grad (the model's flat gradient buffer, n entries) receives the entries grad_idx names (inv_idx, optional: the inverse table
-// [part_floats] position -> parameter or -1, for the layout-order reduction); out8 / loss_f32 / accum / state as vpc_nm_loss.  part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (vpc_nmdec_layout).
-int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
-                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx, float* grad,
-                   int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
-                   int K, int d, int L, double alpha, void* stream) {
-    if (!img || !x || !mask || !heads || !eps || !dht || !part || !stat_part || !grad_idx || !grad || !out8) return VPC_ERR_ARG;
+// launches the tile kernel of vpc_nmdec_step; *blocks_out = the partial blocks it writes
+static int nmdec_launch_tiles(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
+                              const float* eps, float* dht, float* part, double* stat_part, long B, long B_global, int K, int d, int L,
+                              double alpha, hipStream_t st, int* blocks_out) {
+    if (!img || !x || !mask || !heads || !eps || !dht || !part || !stat_part) return VPC_ERR_ARG;
     const int reg = mask_p != nullptr;  // NULL: notMIWAE_myversion (one pass; eps = [B K][L] draws, then the [B K][L] draws of its KL)
     if (!reg) alpha = 0.0;
     if (B <= 0 || B_global < B || ldh < 2 * L || B * (long)K > 0x3fffff00L) return VPC_ERR_ARG;
@@ -1315,7 +1308,6 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
 #endif
     const int cap = num_cus();
     const int blocks = a.ntiles < cap ? a.ntiles : cap;
-    hipStream_t st = (hipStream_t)stream;
     if (reg) {
         if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8, true>), ND_LDS)) return VPC_ERR_HIP;
         hipLaunchKernelGGL((nmdec_kernel<8, true>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
@@ -1323,13 +1315,80 @@ int vpc_nmdec_step(const float* img, const float* x, const float* mask, const fl
         if (!lds_attr_done(reinterpret_cast<const void*>(nmdec_kernel<8, false>), ND_LDS)) return VPC_ERR_HIP;
         hipLaunchKernelGGL((nmdec_kernel<8, false>), dim3(blocks), dim3(ND_THREADS), ND_LDS, st, a);
     }
-    if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
+    *blocks_out = blocks;
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+// launches the tile kernel of vpc_nmenc_bwd
+static int nmenc_launch_bwd(const float* img, const float* xin, const float* h1, const float* h2, const float* dht, float* part,
+                            long part_floats, long R, int d, int L, hipStream_t st, int* blocks_out) {
+    if (!img || !xin || !h1 || !h2 || !dht || !part || R <= 0) return VPC_ERR_ARG;
+    if (!nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(xin) | reinterpret_cast<uintptr_t>(h1) |
+         reinterpret_cast<uintptr_t>(h2) | reinterpret_cast<uintptr_t>(part)) & 15)
+        return VPC_ERR_ARG;
+    const long tiles = (R + ND_ROWS - 1) / ND_ROWS;
+    long blocks = num_cus();  // (478 registers per lane: one workgroup per CU)
+    if (tiles < blocks) blocks = tiles;
+    if (part_floats / NEB_PART < blocks) blocks = part_floats / NEB_PART;
+    if (blocks < 1) return VPC_ERR_ARG;
+    NmebArgs a{img + NdImg::total, xin, h1, h2, dht, part, R, L};
+    if (!lds_attr_done(reinterpret_cast<const void*>(nmenc_bwd_kernel), NEB_LDS)) return VPC_ERR_HIP;
+    hipLaunchKernelGGL(nmenc_bwd_kernel, dim3((unsigned)blocks), dim3(ND_THREADS), NEB_LDS, st, a);
+    *blocks_out = (int)blocks;
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// The fused decoder + loss + decoder backward of one regularised MNAR step (two launches: the tile kernel and the fixed-order
+// reduction of its partial blocks).  heads [2 B][ldh] = the encoder's (mean | logvar) rows of the q pass, then of the p pass;
+// eps [2 B K][L]; dht [2 B][2 L] receives the gradient w.r.t. heads (K-fold sum of dz + the analytic KL gradients);
+// grad (the model's flat gradient buffer, n entries) receives the entries grad_idx names (inv_idx, optional: the inverse table
+// [part_floats] position -> parameter or -1, for the layout-order reduction); out8 / loss_f32 / accum / state as vpc_nm_loss.  part: max_blocks x part_floats floats, stat_part: max_blocks x 5 doubles (vpc_nmdec_layout).
+int vpc_nmdec_step(const float* img, const float* x, const float* mask, const float* mask_p, const float* heads, long ldh,
+                   const float* eps, float* dht, float* part, double* stat_part, const int* grad_idx, const int* inv_idx, float* grad,
+                   int n, double* out8, float* loss_f32, float* accum, long long* state, long long rng_inc, long B, long B_global,
+                   int K, int d, int L, double alpha, void* stream) {
+    if (!grad_idx || !grad || !out8) return VPC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = 0;
+    const int rc = nmdec_launch_tiles(img, x, mask, mask_p, heads, ldh, eps, dht, part, stat_part, B, B_global, K, d, L, alpha, st, &blocks);
+    if (rc != VPC_OK) return rc;
+    const int reg = mask_p != nullptr;
     NmdFinArgs f{};
     f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.grad_idx = grad_idx; f.inv_idx = inv_idx; f.grad = grad; f.n = n;
-    f.B = (int)B; f.K = K; f.L = L; f.reg = reg; f.alpha = alpha; f.inv_B = 1.0 / Bg;
+    f.B = (int)B; f.K = K; f.L = L; f.reg = reg; f.alpha = reg ? alpha : 0.0; f.inv_B = 1.0 / (double)B_global;
     f.out = out8; f.loss_f32 = loss_f32; f.accum = accum; f.state = state; f.rng_inc = rng_inc;
-    const int fin_grid = 1 + (inv_idx ? (ND_PART / 4 + 7) / 8 : (n + 255) / 256);
+    const int fin_grid = 1 + (inv_idx ? ND_FIN_BLOCKS : (n + 255) / 256);
     hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(fin_grid), dim3(256), 0, st, f);
+    return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
+}
+
+// Everything behind the encoder forward of a single-device MNAR step in THREE launches: the decoder tile kernel (vpc_nmdec_step's),
+// the encoder-backward tile kernel (vpc_nmenc_bwd's) and ONE tail launch that sums both sets of partial blocks into grad, applies Adam
+// (torch.optim.Adam as vpc_adam_step: train.py:21,116) to every gradient it finishes, re-packs the parameter's place in the bf16
+// image (pack_idx of vpc_nmdec_build_indices) and writes the loss terms.  Arguments as vpc_nmdec_step + vpc_nmenc_bwd; part_e:
+// max_blocks x the encoder's part_floats (vpc_nmenc_build_indices), its own buffer here: both sets are live until the tail.
+int vpc_nm_fused_bwd_step(float* img, const float* x, const float* mask, const float* mask_p, const float* xin, const float* h1,
+                          const float* h2, const float* heads, long ldh, const float* eps, float* dht, float* part,
+                          double* stat_part, float* part_e, long part_e_floats, const int* inv_idx, const int* inv_idx_e,
+                          float* grad, int n, double* out8, float* loss_f32, float* accum, long B, long B_global, int K, int d,
+                          int L, double alpha, float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                          float beta2, float eps_adam, long step, const int* pack_idx, void* stream) {
+    if (!inv_idx || !inv_idx_e || !grad || !out8 || !params || !exp_avg || !exp_avg_sq || !pack_idx || step < 1) return VPC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int reg = mask_p != nullptr;
+    int blocks = 0, blocks_e = 0;
+    int rc = nmdec_launch_tiles(img, x, mask, mask_p, heads, ldh, eps, dht, part, stat_part, B, B_global, K, d, L, alpha, st, &blocks);
+    if (rc != VPC_OK) return rc;
+    rc = nmenc_launch_bwd(img, xin, h1, h2, dht, part_e, part_e_floats, (reg ? 2 : 1) * B, d, L, st, &blocks_e);
+    if (rc != VPC_OK) return rc;
+    NmdFinArgs f{};
+    f.part = part; f.stat_part = stat_part; f.n_blocks = blocks; f.inv_idx = inv_idx; f.grad = grad; f.n = n;
+    f.B = (int)B; f.K = K; f.L = L; f.reg = reg; f.alpha = reg ? alpha : 0.0; f.inv_B = 1.0 / (double)B_global;
+    f.out = out8; f.loss_f32 = loss_f32; f.accum = accum;
+    f.part_e = part_e; f.n_blocks_e = blocks_e; f.inv_idx_e = inv_idx_e;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    f.adam = AdamFuse{params, exp_avg, exp_avg_sq, pack_idx, img, lr, beta1, beta2, eps_adam, (float)bc1, (float)std::sqrt(bc2), 1};
+    hipLaunchKernelGGL(nmdec_finalize_kernel, dim3(1 + ND_FIN_BLOCKS + NE_FIN_BLOCKS), dim3(256), 0, st, f);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 
@@ -1356,22 +1415,12 @@ int vpc_nmenc_fwd(const float* img, const float* xin, float* h1, float* h2, floa
 // serve: vpc_nmdec_layout's max_blocks x part_floats is always enough for one block per 64-row tile or one per CU).
 int vpc_nmenc_bwd(const float* img, const float* xin, const float* h1, const float* h2, const float* dht, float* part,
                   long part_floats, const int* inv_idx, float* grad, long R, int d, int L, void* stream) {
-    if (!img || !xin || !h1 || !h2 || !dht || !part || !inv_idx || !grad || R <= 0) return VPC_ERR_ARG;
-    if (!nmdec_shape_ok(8, d, L)) return VPC_ERR_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(xin) | reinterpret_cast<uintptr_t>(h1) |
-         reinterpret_cast<uintptr_t>(h2) | reinterpret_cast<uintptr_t>(part)) & 15)
-        return VPC_ERR_ARG;
-    const long tiles = (R + ND_ROWS - 1) / ND_ROWS;
-    long blocks = num_cus();  // (290 registers per lane: one workgroup per CU)
-    if (tiles < blocks) blocks = tiles;
-    if (part_floats / NEB_PART < blocks) blocks = part_floats / NEB_PART;
-    if (blocks < 1) return VPC_ERR_ARG;
-    NmebArgs a{img + NdImg::total, xin, h1, h2, dht, part, R, L};
+    if (!inv_idx || !grad) return VPC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (!lds_attr_done(reinterpret_cast<const void*>(nmenc_bwd_kernel), NEB_LDS)) return VPC_ERR_HIP;
-    hipLaunchKernelGGL(nmenc_bwd_kernel, dim3((unsigned)blocks), dim3(ND_THREADS), NEB_LDS, st, a);
-    if (hipGetLastError() != hipSuccess) return VPC_ERR_HIP;
-    hipLaunchKernelGGL(nmenc_reduce_kernel, dim3((NEB_PART / 4 + 7) / 8), dim3(256), 0, st, part, (int)blocks, inv_idx, grad);
+    int blocks = 0;
+    const int rc = nmenc_launch_bwd(img, xin, h1, h2, dht, part, part_floats, R, d, L, st, &blocks);
+    if (rc != VPC_OK) return rc;
+    hipLaunchKernelGGL(nmenc_reduce_kernel, dim3(NE_FIN_BLOCKS), dim3(256), 0, st, part, blocks, inv_idx, grad);
     return hipGetLastError() == hipSuccess ? VPC_OK : VPC_ERR_HIP;
 }
 

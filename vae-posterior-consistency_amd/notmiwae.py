@@ -147,6 +147,15 @@ def nmenc_bwd(img, xin, h1, h2, dht, part, inv, grad, R, d, Ld):
                               R, d, Ld, stream_ptr()), "vpc_nmenc_bwd")
 
 
+def nm_fused_bwd_step(img, x, mask, mask_p, xin, h1, h2, heads, eps, dht, part, stat, part_e, inv, inv_e, grad, out8, loss_f32, accum,
+                      B, B_global, K, d, Ld, alpha, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps_adam, step, pack_idx):
+    check(lib().vpc_nm_fused_bwd_step(ptr(img), ptr(x), ptr(mask), ptr(mask_p), ptr(xin), ptr(h1), ptr(h2), ptr(heads), 2 * Ld,
+                                      ptr(eps), ptr(dht), ptr(part), ptr(stat), ptr(part_e), part_e.numel(), ptr(inv), ptr(inv_e),
+                                      ptr(grad), grad.numel(), ptr(out8), ptr(loss_f32), ptr(accum), B, B_global, K, d, Ld,
+                                      float(alpha), ptr(params), ptr(exp_avg), ptr(exp_avg_sq), lr, beta1, beta2, eps_adam,
+                                      int(step), ptr(pack_idx), stream_ptr()), "vpc_nm_fused_bwd_step")
+
+
 def nmdec_step(img, x, mask, mask_p, heads, eps, dht, part, stat, gidx, inv, grad, out8, loss_f32, accum, B, B_global, K, d,
                Ld, alpha, state=None, rng_inc=0):
     check(lib().vpc_nmdec_step(ptr(img), ptr(x), ptr(mask), ptr(mask_p), ptr(heads), 2 * Ld, ptr(eps), ptr(dht),
@@ -612,6 +621,15 @@ class NMTrainer:
             off += p.numel()
         self._B = None
         self.timers = None
+        # the bf16 image of the layer-fused path is current when nothing has written the parameters since the launch that packed it
+        # (the fused tail of a single-device step re-packs what its Adam updates): the flat buffer's address + the parameters'
+        # version counters at that time.  Writes torch does not count (p.data.copy_, raw kernels): call invalidate_image().
+        self._plist = model.trainable()
+        self._img_key = None
+
+    def invalidate_image(self):
+        """Force a re-pack of the bf16 weight image at the next step (after writing parameters behind torch's version counters)."""
+        self._img_key = None
 
     def _ws(self, B):
         if self._B == B:
@@ -659,6 +677,7 @@ class NMTrainer:
                 self._nd_tables = nmdec_tables(m, dev)
                 self.nd_img = torch.zeros(nimg.value, device=dev)
             self.nd_part = e(nblk.value * npart.value)
+            self.ne_part = e(nblk.value * int(self._nd_tables[3].numel()))  # the encoder-backward kernel's blocks (fused tail)
             self.nd_stat = torch.empty(nblk.value * 5, dtype=torch.float64, device=dev)
         self._B = B
 
@@ -714,11 +733,17 @@ class NMTrainer:
             self.eps.copy_(eps)
         self.rng_offset += rng_inc
         # ---- forward
+        # single device, eager: everything behind the encoder forward is three launches (decoder tiles, encoder-backward tiles, one tail
+        # that reduces both sets of blocks, applies Adam and re-packs the image: vpc_nm_fused_bwd_step) and the pack launch goes
+        fuse_tail = self.use_nmdec and self.world_size == 1 and _state is None and self.timers is None
         if self.use_nmdec:
             # plain bf16 at obs_dim 128: ONE image (decoder, missingness model, encoder) packed by one launch, the encoder forward
             # as one kernel (csrc/vpc_nmdec.hip: nmenc_fwd_kernel) instead of three GEMM launches
-            from .ops import step_pack_weights_bf16
-            t("pack", step_pack_weights_bf16, m._flat, self._nd_tables[0], self.nd_img)
+            key = (m._flat.data_ptr(), tuple(p._version for p in self._plist)) if fuse_tail else None
+            if key is None or key != self._img_key:
+                from .ops import step_pack_weights_bf16
+                t("pack", step_pack_weights_bf16, m._flat, self._nd_tables[0], self.nd_img)
+            self._img_key = None  # (whoever updates the parameters below says whether the image followed)
             t("enc_fwd", nmenc_fwd, self.nd_img, self.xin, self.h1, self.h2, self.heads, R, d, Ld)
         else:
             t("enc_fwd", linear_fwd, self.xin, v["We1"], v["be1"], self.h1, R, HID, d, ACT_ELU, precision=self.prec)
@@ -741,6 +766,14 @@ class NMTrainer:
             # K-fold rsample, decoder, loss, decoder backward and the K-fold sum of dz in ONE kernel (csrc/vpc_nmdec.hip): the
             # decoder / missingness-model gradients land in self.grad, d loss / d heads in self.dht
             pidx, gidx, ginv, einv = self._nd_tables
+            if fuse_tail:
+                self.step_count += 1
+                nm_fused_bwd_step(self.nd_img, xf, mf, mp, self.xin, self.h1, self.h2, self.heads, self.eps, self.dht, self.nd_part,
+                                  self.nd_stat, self.ne_part, ginv, einv, self.grad, self.out8, self.loss, self.accum, B, Bg, K, d,
+                                  Ld, alpha, m._flat, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                                  self.eps_adam, self.step_count, pidx)
+                self._img_key = key
+                return
             t("dec_fused", nmdec_step, self.nd_img, xf, mf, mp, self.heads, self.eps, self.dht, self.nd_part, self.nd_stat,
               gidx, ginv, self.grad, self.out8, self.loss, self.accum if self.world_size == 1 else None, B, Bg, K, d, Ld, alpha,
               _state, rng_inc)
