@@ -983,12 +983,12 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         const int r = 16 * w + cc, fl = 16 * qq + cc;
         const long nxt = tile + gridDim.x;
         const Op dhb[1] = {nd_pack2(d0, d1)};
-        ND_BARRIER();  // (the previous tile's last round is read)
+        lds_barrier();  // (the previous tile's last round is read)
         // ---- Rh: dWh = dht^T h2, dbh   [dht 0-1 | h2 8-15]
         nd_st_op<true, NE_FT>(st, r, 0, 0, qq, dhb[0]);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf2[2 * kb], hf2[2 * kb + 1]));
-        ND_BARRIER();
+        lds_barrier();
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
             const Op fa0 = nd_st_frag<NE_FT>(st, 0, kb, fl), fa1 = nd_st_frag<NE_FT>(st, 1, kb, fl);
@@ -1007,14 +1007,14 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         });
         launder(cc, qq);
         if (nxt < ntiles) { req_d(nxt); req(hf2, a.h2, nxt); }
-        ND_BARRIER();  // (Rh is read)
+        lds_barrier();  // (Rh is read)
         // ---- R2: dW2 = dh2^T h1, db2   [dh2 0-7 | h1 8-15]
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             nd_st_op<true, NE_FT>(st, r, 0, kb, qq, dh2b[kb]);
             nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hf1[2 * kb], hf1[2 * kb + 1]));
         }
-        ND_BARRIER();
+        lds_barrier();
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
             Op fb[8];
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
         });
         launder(cc, qq);
         if (nxt < ntiles) req(hf1, a.h1, nxt);
-        ND_BARRIER();  // (R2 is read)
+        lds_barrier();  // (R2 is read)
         // ---- R1: dW1 = dh1^T x, db1   [dh1 0-7 | x * mask 8-15]
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmenc_bwd_kernel(NmebArgs a) {
             nd_st_op<true, NE_FT>(st, r, 8, kb, qq, nd_pack2(hfx[2 * kb], hfx[2 * kb + 1]));
         }
         if (nxt < ntiles) req(hfx, a.xin, nxt);
-        ND_BARRIER();
+        lds_barrier();
 #pragma unroll
         for (int kb = 0; kb < ND_ROWS / 32; ++kb) {
             Op fb[8];
