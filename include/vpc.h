@@ -410,7 +410,8 @@ int vpc_eddi_front_bwd(const float* x, const uint8_t* mask, const uint8_t* mask2
  * vpc_encoder_bwd / vpc_decoder_fused (*nblocks_out blocks each), so vpc_reduce_step(_adam) consumes them unchanged.
  * The kernel runs two sweeps over a workgroup's tiles (decoder-side gradients, then encoder-side gradients: csrc/vpc_step.hip);
  * the seeds on (mean | logvar) cross from one to the other through `workspace` as packed bf16, 16 bytes per lane. */
-/* 1 when the library runs a (B, d, L, npass) bf16 step through vpc_step_fused_bf16 (throughput workgroup shape), else 0 */
+/* 1 when the library runs a (B, d, L, npass) plain-bf16 step through vpc_step_fused_bf16: obs_dim in (64, 128], obs_dim % 4 == 0, any
+ * batch (VPC_TILE=64 / VPC_STEP_FUSED=0 in the environment: the three small-shape kernels, for A/B runs), else 0 */
 int vpc_step_fused_applicable(long B, int d, int L, int npass);
 /* floats of the caller-owned `workspace` of vpc_step_fused_bf16 for B rows (16-byte aligned; contents are scratch) */
 long vpc_step_workspace_floats(long B);

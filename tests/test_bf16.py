@@ -113,11 +113,12 @@ def test_vanilla_step_vs_reference_vectors(prec):
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("d,B,tile", [(128, 1000, "auto"), (100, 300, "auto"), (72, 129, "128"), (128, 65536, "auto"),
                                       (128, 1000, "128"), (40, 300, "auto"), (64, 20000, "auto"), (16, 100, "128"),
-                                      (128, 8192, "auto")])
+                                      (128, 8192, "auto"), (128, 1000, "64"), (100, 300, "64"), (128, 8192, "64")])
 def test_ragged_and_full_size_vs_f32_path(prec, d, B, tile, monkeypatch):
     """Against the fp32 kernels on the same inputs (themselves checked against the oracle at these shapes), in both
-    workgroup shapes ("auto" = the library's choice: the small-batch shape up to B = 16 384; "128" = the throughput shape
-    forced) and for the narrower models (d <= 64 runs the 4-wave decoder kernel in either shape)."""
+    workgroup shapes ("auto" = the library's choice: the small-batch shape up to B = 16 384 - for plain bf16 at d > 64 the
+    whole-step kernel at every batch; "64" / "128" = a shape forced) and for the narrower models (d <= 64 runs the 4-wave
+    decoder kernel in either shape)."""
     if tile != "auto":
         monkeypatch.setenv("VPC_TILE", tile)
     params = O.init_params(d, L, seed=7)

@@ -112,10 +112,11 @@ def _t(a):
     ("a05", dict(alpha=0.5, beta=0.7, beta_annealing=True, epoch=1400)),
     ("ml", dict(alpha=0.8, beta=1.0, beta_annealing=False, epoch=1400)),
 ])
-@pytest.mark.parametrize("tile", ["auto", "128"])
+@pytest.mark.parametrize("tile", ["auto", "64", "128"])
 def test_reg_step_on_reference_vectors(prec, tag, kw, tile, monkeypatch):
     """reg_d128.npz inputs (the reference's own), both workgroup shapes: the 64-row fixture runs the small-batch kernels
-    by default and the throughput kernels (incl. the fused step kernel for plain bf16) with VPC_TILE=128."""
+    with VPC_TILE=64 and the throughput kernels with VPC_TILE=128; plain bf16 runs the whole-step kernel unless VPC_TILE=64
+    (VPC_STEP_SMALL=0 is set for this module: otherwise 64 rows would go to the fp32 N-split kernel)."""
     if tile != "auto":
         monkeypatch.setenv("VPC_TILE", tile)
     g = load_golden("reg_d128.npz")
@@ -128,13 +129,13 @@ def test_reg_step_on_reference_vectors(prec, tag, kw, tile, monkeypatch):
     loss, grads, _, _ = O.closed_form_reg_step(P, L, g["x"], g["mask"], g["mask_p"], g["eps_q"], g["eps_p"], reg_type=rt,
                                                eps_ml=g["eps_ml"] if tag == "ml" else None, gemm=prec,
                                                db1_rounded=tr._used_step_fused, **kw)
-    assert tr._used_step_fused == (prec == "bf16" and tile == "128")  # the whole-step kernel is what ran there
+    assert tr._used_step_fused == (prec == "bf16" and tile != "64")  # the whole-step kernel is what ran there
     _check(tr, m, loss, grads)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("tile", ["auto", "128"])
+@pytest.mark.parametrize("tile", ["auto", "64", "128"])
 def test_vanilla_step_on_reference_vectors(prec, tile, monkeypatch):
     if tile != "auto":
         monkeypatch.setenv("VPC_TILE", tile)
@@ -145,17 +146,17 @@ def test_vanilla_step_on_reference_vectors(prec, tile, monkeypatch):
     tr.step(_t(g["x"]), _t(g["mask"]), eps_q=_t(g["eps_q"]), update=False)
     loss, grads, _ = O.closed_form_vanilla_step(P, L, g["x"], g["mask"], g["eps_q"], gemm=prec,
                                                 db1_rounded=tr._used_step_fused)
-    assert tr._used_step_fused == (prec == "bf16" and tile == "128")
+    assert tr._used_step_fused == (prec == "bf16" and tile != "64")
     _check(tr, m, loss, grads)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("d,B,tile", [(128, 1000, "auto"), (128, 1000, "128"), (100, 300, "128"), (72, 129, "128"),
-                                      (40, 300, "auto"), (16, 100, "128"), (128, 20000, "auto")])
+@pytest.mark.parametrize("d,B,tile", [(128, 1000, "auto"), (128, 1000, "64"), (128, 1000, "128"), (100, 300, "128"), (100, 300, "64"),
+                                      (72, 129, "128"), (40, 300, "auto"), (16, 100, "128"), (128, 20000, "auto")])
 def test_reg_step_ragged_shapes(prec, d, B, tile, monkeypatch):
-    """B = 1 000 and ragged shapes in both workgroup shapes (d <= 64: the 4-wave decoder; d in (64, 128] with VPC_TILE=128
-    or B > 16 384: the 8-wave kernels / the fused bf16 step kernel)."""
+    """B = 1 000 and ragged shapes in both workgroup shapes (d <= 64: the 4-wave decoder; d in (64, 128]: the fused bf16 step kernel
+    unless VPC_TILE=64 keeps the three small-shape kernels; bf16x3: the 8-wave kernels with VPC_TILE=128 or B > 16 384)."""
     if tile != "auto":
         monkeypatch.setenv("VPC_TILE", tile)
     P = O.init_params(d, L, seed=7)
@@ -169,7 +170,7 @@ def test_reg_step_ragged_shapes(prec, d, B, tile, monkeypatch):
     tr.step(x.cuda(), mask.cuda(), mask_p.cuda(), eq.cuda(), ep.cuda(), alpha=0.8, beta=0.9, update=False)
     loss, grads, _, _ = O.closed_form_reg_step(P, L, x.numpy(), mask.numpy(), mask_p.numpy(), eq.numpy(), ep.numpy(),
                                                alpha=0.8, beta=0.9, gemm=prec, db1_rounded=tr._used_step_fused)
-    assert tr._used_step_fused == (prec == "bf16" and d > 64 and (tile == "128" or B > 16384))
+    assert tr._used_step_fused == (prec == "bf16" and d > 64 and tile != "64")
     _check(tr, m, loss, grads)
 
 

@@ -1029,15 +1029,19 @@ static inline int row3c(int o, int L) { return o < L ? o : 16 + (o - L); }
 
 using namespace vpc;
 
-// 1 when vpc_step_fused_bf16 is the form the library runs for this shape: obs_dim in (64, 128], obs_dim % 4 == 0 and the
-// throughput workgroup shape (tile_shape: batches whose 64-row (tile, pass) pairs do not fit two rounds of workgroups, or
-// VPC_TILE=128); the small-batch shape keeps the three 4-wave kernels
+// 1 when vpc_step_fused_bf16 is the form the library runs for this shape: obs_dim in (64, 128], obs_dim % 4 == 0, any batch (the
+// caller routes the smallest batches to vpc_step_small_f32 first).  Mid-size batches too: one 128-row tile per workgroup in ONE launch
+// beats the three small-shape launches (B = 8 192: 55 us against 69, B = 16 384: 58 against 97; profiles/r03_notes.md).
+// VPC_TILE=64 or VPC_STEP_FUSED=0 in the environment keep the three-kernel form (A/B runs, tests of those kernels).
 extern "C" int vpc_step_fused_applicable(long B, int d, int L, int npass) {
     if (d <= 64 || d > MAX_D || d % 4 || L < 1 || L > MAX_L || npass < 1 || npass > 2 || B <= 0) return 0;
     if (const char* e = getenv("VPC_STEP_FUSED")) {
-        if (atoi(e) == 0) return 0;  // A/B runs: the three-kernel form
+        if (atoi(e) == 0) return 0;
     }
-    return tile_shape(B, npass).small ? 0 : 1;
+    if (const char* e = getenv("VPC_TILE")) {
+        if (atoi(e) == 64) return 0;
+    }
+    return 1;
 }
 
 // floats of the caller-owned workspace vpc_step_fused_bf16 needs for a batch of B rows (the packed seeds between its sweeps)
