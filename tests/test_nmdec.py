@@ -311,3 +311,36 @@ def test_fused_tail_equals_separate_launches_and_follows_parameter_writes():
         assert a[0] == b[0], (poke, a[0], b[0])
         assert torch.equal(a[1], b[1]), poke
     assert run(False, None)[0][2:] != run(False, "torch")[0][2:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reg", [True, False])
+def test_fused_vs_gemm_chain_many_tiles_per_workgroup(reg, monkeypatch):
+    """A throughput-sized batch (B = 20 000, K = 20: 6 667 tiles per pass on 256 workgroups - every workgroup loops over ~50 tiles,
+    the last one ragged; the encoder kernels run several tiles per workgroup too): the layer-fused step against the GEMM chain it
+    replaces on the same device-side draws.  Loss to 2e-4 relative, every gradient tensor to 5e-3 of its largest entry (the two forms
+    round the bias gradients and the ELU gates at different points; at this size no single Hardtanh gate matters)."""
+    from vpc_amd import notmiwae as nm
+    B, d, K, L = 20000, 128, 20, 10
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, d, generator=g).cuda()
+    m = (torch.rand(B, d, generator=g) < 0.7).float().cuda()
+    cls = nm.REG_notMIWAE_v2 if reg else nm.notMIWAE_myversion
+    runs = {}
+    for form in ("fused", "gemm"):
+        if form == "gemm":
+            monkeypatch.setenv("VPC_NMDEC", "0")
+        torch.manual_seed(3)
+        model = cls(d, 128, 10, L, {"batch_size": B, "patience": 1}, K, 1).cuda()
+        tr = nm.NMTrainer(model, precision="bf16", seed=11)
+        tr.step(x, m, alpha=0.5, p_missingness=50)
+        assert tr.use_nmdec == (form == "fused")
+        runs[form] = (tr.loss_value(), {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()
+                                        if p.grad is not None})
+        del tr, model
+        torch.cuda.empty_cache()
+    lf, lg = runs["fused"][0], runs["gemm"][0]
+    assert abs(lf - lg) <= 2e-4 * abs(lg), (lf, lg)
+    for k, gg in runs["gemm"][1].items():
+        e = rel(runs["fused"][1][k], gg)
+        assert e < 5e-3, (k, e)
