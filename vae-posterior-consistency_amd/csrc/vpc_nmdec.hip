@@ -387,6 +387,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 *reinterpret_cast<f32x4*>(dst + 512) = -sp * (x4 * m4 - bj);
             } else {
                 *reinterpret_cast<f32x4*>(dst + 128) = p4;
+                *reinterpret_cast<f32x4*>(dst + 256) = zero4();
+                *reinterpret_cast<f32x4*>(dst + 384) = zero4();
+                *reinterpret_cast<f32x4*>(dst + 512) = zero4();
             }
         }
         *reinterpret_cast<f32x4*>(st + ND_EPS + (tid >> 2) * 16 + 4 * (tid & 3)) = pfe;
@@ -486,13 +489,10 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             Elems e;
             e.xv = *reinterpret_cast<const f32x4*>(xin + 16 * t);
             e.mA = *reinterpret_cast<const f32x4*>(xin + 128 + 16 * t);
-            if (qpass) {
-                e.mE = *reinterpret_cast<const f32x4*>(xin + 256 + 16 * t);
-                e.A = *reinterpret_cast<const f32x4*>(xin + 384 + 16 * t);
-                e.C = *reinterpret_cast<const f32x4*>(xin + 512 + 16 * t);
-            } else {
-                e.mE = e.A = e.C = zero4();
-            }
+            // (unconditional: a p-pass tile stores zeros there - a branch here costs 12 register copies per tile at its join)
+            e.mE = *reinterpret_cast<const f32x4*>(xin + 256 + 16 * t);
+            e.A = *reinterpret_cast<const f32x4*>(xin + 384 + 16 * t);
+            e.C = *reinterpret_cast<const f32x4*>(xin + 512 + 16 * t);
             return e;
         };
         // xm = sigmoid(.), xl = hardtanh(., -10, 0) of the lane's 4 features of tile t
@@ -584,40 +584,36 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 f32x4 xm4, xl4;
                 heads_act(t, a0, a1, xm4, xl4);
                 const f32x4 isp = *reinterpret_cast<const f32x4*>(ISP + 16 * t + 4 * qq);
-                f32x4 gm, gl, e1 = zero4(), e2 = zero4();
+                // the missingness model's part (q pass only) in ONE uniform branch, row sums included: only e1A (its term of the
+                // gradient w.r.t. xm) leaves it - values defined on one side of a branch and used behind its join cost a register
+                // copy each, and the common part below is the same expression in both passes (a p tile has mE = A = 0)
+                f32x4 gm, gl, e1A = zero4();
+                if (qpass) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lg = xm4[j] * cur.A[j] + cur.C[j];
+                        const float el2 = __expf(-fabsf(lg)), rc = __builtin_amdgcn_rcpf(1.f + el2);
+                        const float dn = (lg >= 0.f ? rc : el2 * rc) - cur.mA[j];
+                        const float e1 = wgt * dn;
+                        const float e2 = -e1 * lg * isp[j];  // e1 (xm (1 - m) + x m - b): the logit divided back by -softplus(W)
+                        e1A[j] = e1 * cur.A[j];              // (-dn softplus(W) (1 - m) = dn A)
+                        const int e = 4 * t + j;
+                        const float s1 = row_sum_dpp(e1), s2 = row_sum_dpp(e2);
+                        if (cc == (e & 15)) { acc_e1[e >> 4] += s1; acc_e2[e >> 4] += s2; }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xm = xm4[j], xl = xl4[j];
                     const float rr = cur.xv[j] - xm, riv = rr * __expf(-xl);
                     const float h2 = 0.5f - 0.5f * rr * riv;  // d / d xl of the element NLL
-                    const float wA = wgt * cur.mA[j];
-                    float gxm, gxl;
-                    if (qpass) {
-                        const float ee = oe * cur.mE[j];
-                        const float lg = xm * cur.A[j] + cur.C[j];
-                        const float el2 = __expf(-fabsf(lg)), rc = __builtin_amdgcn_rcpf(1.f + el2);
-                        const float dn = (lg >= 0.f ? rc : el2 * rc) - cur.mA[j];
-                        e1[j] = wgt * dn;
-                        gxm = e1[j] * cur.A[j] - (wA + ee) * riv;  // (-dn softplus(W) (1 - m) = dn A)
-                        gxl = (wA + ee) * h2;
-                        e2[j] = -e1[j] * lg * isp[j];  // e1 (xm (1 - m) + x m - b): the logit divided back by -softplus(W)
-                    } else {
-                        gxm = -wA * riv;
-                        gxl = wA * h2;
-                    }
+                    const float wE = wgt * cur.mA[j] + oe * cur.mE[j];
+                    const float gxm = e1A[j] - wE * riv, gxl = wE * h2;
                     gm[j] = gxm * (xm * (1.f - xm));
                     gl[j] = (xl > -10.f && xl < 0.f) ? gxl : 0.f;
                 }
                 gmh[t] = u32x2{pk_bf16(gm[0], gm[1]), pk_bf16(gm[2], gm[3])};
                 glh[t] = u32x2{pk_bf16(gl[0], gl[1]), pk_bf16(gl[2], gl[3])};
-                if (qpass) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = 4 * t + j;
-                        const float s1 = row_sum_dpp(e1[j]), s2 = row_sum_dpp(e2[j]);
-                        if (cc == (e & 15)) { acc_e1[e >> 4] += s1; acc_e2[e >> 4] += s2; }
-                    }
-                }
             });
         }
         Op Gb[DT];
