@@ -500,8 +500,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             const f32x4 p0 = a0 + *reinterpret_cast<const f32x4*>(bx + 16 * t + 4 * qq);
             const f32x4 p1 = a1 + *reinterpret_cast<const f32x4*>(bx + 16 * (DT + t) + 4 * qq);
             xm4 = f32x4{fast_sigmoid(p0[0]), fast_sigmoid(p0[1]), fast_sigmoid(p0[2]), fast_sigmoid(p0[3])};
-            xl4 = f32x4{fminf(fmaxf(p1[0], -10.f), 0.f), fminf(fmaxf(p1[1], -10.f), 0.f), fminf(fmaxf(p1[2], -10.f), 0.f),
-                        fminf(fmaxf(p1[3], -10.f), 0.f)};
+            // Hardtanh(-10, 0) as ONE v_med3_f32 (fminf(fmaxf()) is four instructions with the canonicalisation of its NaN rule)
+            xl4 = f32x4{__builtin_amdgcn_fmed3f(p1[0], -10.f, 0.f), __builtin_amdgcn_fmed3f(p1[1], -10.f, 0.f),
+                        __builtin_amdgcn_fmed3f(p1[2], -10.f, 0.f), __builtin_amdgcn_fmed3f(p1[3], -10.f, 0.f)};
         };
         float sA = 0.f, sE = 0.f, sN = 0.f;
         {
@@ -518,7 +519,9 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     if (qpass) {
                         sE += cur.mE[j] * el;
                         const float lg = xm * cur.A[j] + cur.C[j];  // -softplus(W) (xm (1 - m) + x m - b)
-                        sN += fmaxf(lg, 0.f) - lg * cur.mA[j] + __logf(1.f + __expf(-fabsf(lg)));
+                        // softplus(lg) - lg m; the log's argument is in (1, 2]: v_log_f32 directly (__logf is the full-range
+                        // expansion, 12 instructions with its denormal scaling)
+                        sN += fmaxf(lg, 0.f) - lg * cur.mA[j] + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + __expf(-fabsf(lg)));
                     }
                 }
             });
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     s += (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx));
                 }
             }
-            const float lse = mx + __logf(s);
+            const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(s);  // (s in [1, K])
             wgt = valid ? (qpass ? a.oq : a.op) * __expf(lw - lse) : 0.f;
             if (valid && qq == 0) {
                 if (k == 0) S[qpass ? 0 : 1] += lse;
