@@ -47,7 +47,7 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd(float v, bool second) {
     // hardware exp / rcp (v_exp_f32, v_rcp_f32): |abs err| < 2e-7 on outputs in (-1, 1)
     if (ACT == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
-    if (ACT == ACT_SIGMOID_HARDTANH) return second ? fminf(fmaxf(v, -10.f), 0.f) : __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    if (ACT == ACT_SIGMOID_HARDTANH) return second ? __builtin_amdgcn_fmed3f(v, -10.f, 0.f) : __builtin_amdgcn_rcpf(1.f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.f);
     return v;
 }

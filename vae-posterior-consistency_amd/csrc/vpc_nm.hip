@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void nm_loss_kernel(NMLossArgs a) {
                 const float mixv = xm * (1.f - m[t]) + x[t] * m[t];
                 const float lg = -sp[t] * (mixv - bj[t]);
                 const float el2 = fexp(-fabsf(lg)), rc = frcp(1.f + el2);
-                s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + __logf(1.f + el2) : 0.f;
+                s_nlp += ok ? fmaxf(lg, 0.f) - lg * m[t] + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + el2) : 0.f;  // (argument in (1, 2]: v_log_f32)
                 dn[t] = (lg >= 0.f ? rc : el2 * rc) - m[t];
                 if (REG) {
                     const float xmp = f.xmp[t];
