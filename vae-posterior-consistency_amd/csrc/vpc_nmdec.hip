@@ -236,8 +236,9 @@ __device__ __forceinline__ f32x4 elu_gate(f32x4 dy, Op act, int second) {
     const uint32_t w0 = second ? h[2] : h[0], w1 = second ? h[3] : h[1];
     const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xffff0000u);
     const float a2 = __uint_as_float(w1 << 16), a3 = __uint_as_float(w1 & 0xffff0000u);
-    return f32x4{a0 > 0.f ? dy[0] : dy[0] * (a0 + 1.f), a1 > 0.f ? dy[1] : dy[1] * (a1 + 1.f),
-                 a2 > 0.f ? dy[2] : dy[2] * (a2 + 1.f), a3 > 0.f ? dy[3] : dy[3] * (a3 + 1.f)};
+    // ELU' = 1 where the activation is positive, else activation + 1 (<= 1 there): min(a + 1, 1) - add, min, multiply instead of add,
+    // multiply, compare, select; the same value in both branches
+    return f32x4{dy[0] * fminf(a0 + 1.f, 1.f), dy[1] * fminf(a1 + 1.f, 1.f), dy[2] * fminf(a2 + 1.f, 1.f), dy[3] * fminf(a3 + 1.f, 1.f)};
 }
 
 // sum over the 16 lanes of a DPP row (the 16 batch rows of a lane group): every lane gets it.  The DPP operand is written as part of
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 const float* hq = a.heads + (long)eb * a.ldh;
                 const float* hp = a.heads + ((long)a.B + eb) * a.ldh;
                 const float mu_q = hq[l], lv_q = hq[L + l], mu_p = hp[l], lv_p = hp[L + l];
-                const float eq = expf(lv_q), ep = expf(lv_p), ivp = expf(-lv_p), ratio = expf(lv_q - lv_p);
+                const float eq = __expf(lv_q), ep = __expf(lv_p), ivp = __expf(-lv_p), ratio = __expf(lv_q - lv_p);  // (v_exp_f32: 2 ulp)
                 const float dm = mu_q - mu_p;
                 const bool first = col < 16;  // mean lanes also carry the statistics
                 float g;
