@@ -261,6 +261,32 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
     return t;
 }
 
+// four such sums at once, interleaved: every DPP add reads a register written three instructions earlier, so the two wait states
+// the hazard asks for are filled with the other sums' adds instead of s_nop (one s_nop 1 in front of the first round only)
+__device__ __forceinline__ void row_sum_dpp4(float (&v)[4]) {
+    float t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    v[0] = t0; v[1] = t1; v[2] = t2; v[3] = t3;
+}
+
 #ifdef VPC_ABLATE
 #define ND_BARRIER() do { if (!(a.dbg & 2)) lds_barrier(); } while (0)
 #define NSTP(i) VPC_STAMP(i)
@@ -593,17 +619,22 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 // copy each, and the common part below is the same expression in both passes (a p tile has mE = A = 0)
                 f32x4 gm, gl, e1A = zero4();
                 if (qpass) {
+                    float e1[4], e2[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float lg = xm4[j] * cur.A[j] + cur.C[j];
                         const float el2 = __expf(-fabsf(lg)), rc = __builtin_amdgcn_rcpf(1.f + el2);
                         const float dn = (lg >= 0.f ? rc : el2 * rc) - cur.mA[j];
-                        const float e1 = wgt * dn;
-                        const float e2 = -e1 * lg * isp[j];  // e1 (xm (1 - m) + x m - b): the logit divided back by -softplus(W)
-                        e1A[j] = e1 * cur.A[j];              // (-dn softplus(W) (1 - m) = dn A)
+                        e1[j] = wgt * dn;
+                        e2[j] = -e1[j] * lg * isp[j];  // e1 (xm (1 - m) + x m - b): the logit divided back by -softplus(W)
+                        e1A[j] = e1[j] * cur.A[j];     // (-dn softplus(W) (1 - m) = dn A)
+                    }
+                    row_sum_dpp4(e1);
+                    row_sum_dpp4(e2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
                         const int e = 4 * t + j;
-                        const float s1 = row_sum_dpp(e1), s2 = row_sum_dpp(e2);
-                        if (cc == (e & 15)) { acc_e1[e >> 4] += s1; acc_e2[e >> 4] += s2; }
+                        if (cc == (e & 15)) { acc_e1[e >> 4] += e1[j]; acc_e2[e >> 4] += e2[j]; }
                     }
                 }
 #pragma unroll
