@@ -113,15 +113,18 @@ __device__ __forceinline__ Op nd_wfrag_T(const float* W, int mt, int kb, int lan
 }
 // forward layer, TWO out tiles per step (two independent MFMA chains: one wave per SIMD has nothing else to cover the dependent
 // latency with); the fragments of the next pair are requested behind the MFMAs of this one
+// (bias: the lane's part of the layer's fp32 bias, bias + 4 q - the accumulators START from it, so the sink has no add to do; nullptr:
+// they start from zero)
 template <int KP, int KB, int NT, typename F>
-__device__ __forceinline__ void nd_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink) {
+__device__ __forceinline__ void nd_layer_fwd(const float* W, const Op (&in)[KB], int m, int q, F&& sink, const float* bias = nullptr) {
     static_assert(NT % 2 == 0, "");
     Op c0[KB], c1[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) { c0[kb] = nd_wfrag<KP>(W, 0, kb, m, q); c1[kb] = nd_wfrag<KP>(W, 1, kb, m, q); }
 #pragma unroll
     for (int mt = 0; mt < NT; mt += 2) {
-        f32x4 a0 = zero4(), a1 = zero4();
+        f32x4 a0 = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * mt) : zero4();
+        f32x4 a1 = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * mt + 16) : zero4();
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) { a0 = VPC_MFMA_BF(c0[kb], in[kb], a0); a1 = VPC_MFMA_BF(c1[kb], in[kb], a1); }
         if (mt + 2 < NT) {
@@ -187,15 +190,17 @@ __device__ __forceinline__ void nd_layer_T(const float* W, const Op (&in)[KB], i
 // the two heads, tile by tile: out tiles t (mean head) and DT + t (log-variance head) as two MFMA chains; pre(t) runs BEFORE the
 // tile's MFMAs (LDS reads issued there arrive under them), sink(t, mean tile, logvar tile) after; the next tile's weight
 // fragments are requested behind the MFMAs
+// (bm / bl: the lane's part of the two heads' biases - the accumulators start from them)
 template <int DT, typename P, typename F>
-__device__ __forceinline__ void nd_heads(const float* W, const Op (&in)[4], int m, int q, P&& pre, F&& sink) {
+__device__ __forceinline__ void nd_heads(const float* W, const Op (&in)[4], int m, int q, P&& pre, F&& sink, const float* bm,
+                                         const float* bl) {
     Op c0[4], c1[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { c0[kb] = nd_wfrag<128>(W, 0, kb, m, q); c1[kb] = nd_wfrag<128>(W, DT, kb, m, q); }
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
         pre(t);
-        f32x4 a0 = zero4(), a1 = zero4();
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(bm + 16 * t), a1 = *reinterpret_cast<const f32x4*>(bl + 16 * t);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) { a0 = VPC_MFMA_BF(c0[kb], in[kb], a0); a1 = VPC_MFMA_BF(c1[kb], in[kb], a1); }
         if (t + 1 < DT) {
@@ -488,10 +493,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         const Op zin[1] = {zb};
         auto make_g1 = [&](Op (&g1b)[4]) {
             nd_layer_fwd<32, 1, ND_HT>(W1, zin, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
-                const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 4 * qq));
-                const f32x4 h1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b1 + 16 * mt + 16 + 4 * qq));
-                g1b[mt >> 1] = nd_pack2(h0, h1);
-            });
+                g1b[mt >> 1] = nd_pack2(elu4(a0), elu4(a1));
+            }, b1 + 4 * qq);
         };
         Op g2b[4];
         {
@@ -499,10 +502,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             make_g1(g1b);
             launder(cc, qq);
             nd_layer_fwd<128, 4, ND_HT>(W2, g1b, cc, qq, [&](int mt, f32x4 a0, f32x4 a1) {
-                const f32x4 h0 = elu4(a0 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 4 * qq));
-                const f32x4 h1 = elu4(a1 + *reinterpret_cast<const f32x4*>(b2 + 16 * mt + 16 + 4 * qq));
-                g2b[mt >> 1] = nd_pack2(h0, h1);
-            });
+                g2b[mt >> 1] = nd_pack2(elu4(a0), elu4(a1));
+            }, b2 + 4 * qq);
         }
         launder(cc, qq);
         VPC_CUT();
@@ -523,9 +524,8 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
             return e;
         };
         // xm = sigmoid(.), xl = hardtanh(., -10, 0) of the lane's 4 features of tile t
-        auto heads_act = [&](int t, f32x4 a0, f32x4 a1, f32x4& xm4, f32x4& xl4) {
-            const f32x4 p0 = a0 + *reinterpret_cast<const f32x4*>(bx + 16 * t + 4 * qq);
-            const f32x4 p1 = a1 + *reinterpret_cast<const f32x4*>(bx + 16 * (DT + t) + 4 * qq);
+        // (a0 / a1 arrive with the heads' biases in them: nd_heads starts its accumulators from bx)
+        auto heads_act = [&](int t, f32x4 p0, f32x4 p1, f32x4& xm4, f32x4& xl4) {
             xm4 = f32x4{fast_sigmoid(p0[0]), fast_sigmoid(p0[1]), fast_sigmoid(p0[2]), fast_sigmoid(p0[3])};
             // Hardtanh(-10, 0) as ONE v_med3_f32 (fminf(fmaxf()) is four instructions with the canonicalisation of its NaN rule)
             xl4 = f32x4{__builtin_amdgcn_fmed3f(p1[0], -10.f, 0.f), __builtin_amdgcn_fmed3f(p1[1], -10.f, 0.f),
@@ -541,17 +541,17 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const float xm = xm4[j], xl = xl4[j];
                     const float rr = cur.xv[j] - xm, riv = rr * __expf(-xl);
-                    const float el = 0.5f * xl + 0.5f * rr * riv;
-                    sA += cur.mA[j] * el;
+                    const float el = fmaf(rr, riv, xl);  // 2 x the element NLL (without its constant): the halves are taken once, below
+                    sA = fmaf(cur.mA[j], el, sA);
                     if (qpass) {
-                        sE += cur.mE[j] * el;
+                        sE = fmaf(cur.mE[j], el, sE);
                         const float lg = xm * cur.A[j] + cur.C[j];  // -softplus(W) (xm (1 - m) + x m - b)
                         // softplus(lg) - lg m; the log's argument is in (1, 2]: v_log_f32 directly (__logf is the full-range
                         // expansion, 12 instructions with its denormal scaling)
                         sN += fmaxf(lg, 0.f) - lg * cur.mA[j] + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + __expf(-fabsf(lg)));
                     }
                 }
-            });
+            }, bx + 4 * qq, bx + 16 * DT + 4 * qq);
         }
         launder(cc, qq);
         VPC_CUT();
@@ -560,6 +560,7 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
         // exchange ends up in scratch: the asm makes its operand a new value)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) asm volatile("" : "+v"(g2b[kb]));
+        sA *= 0.5f; sE *= 0.5f;
         sA += __shfl_xor(sA, 16, 64); sA += __shfl_xor(sA, 32, 64);
         if (qpass) {
             sE += __shfl_xor(sE, 16, 64); sE += __shfl_xor(sE, 32, 64);
@@ -644,12 +645,12 @@ __global__ __launch_bounds__(ND_THREADS) void nmdec_kernel(NmdArgs a) {
                     const float h2 = 0.5f - 0.5f * rr * riv;  // d / d xl of the element NLL
                     const float wE = wgt * cur.mA[j] + oe * cur.mE[j];
                     const float gxm = e1A[j] - wE * riv, gxl = wE * h2;
-                    gm[j] = gxm * (xm * (1.f - xm));
+                    gm[j] = gxm * fmaf(-xm, xm, xm);  // Sigmoid' = xm (1 - xm)
                     gl[j] = (xl > -10.f && xl < 0.f) ? gxl : 0.f;
                 }
                 gmh[t] = u32x2{pk_bf16(gm[0], gm[1]), pk_bf16(gm[2], gm[3])};
                 glh[t] = u32x2{pk_bf16(gl[0], gl[1]), pk_bf16(gl[2], gl[3])};
-            });
+            }, bx + 4 * qq, bx + 16 * DT + 4 * qq);
         }
         Op Gb[DT];
 #pragma unroll
